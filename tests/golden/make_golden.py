@@ -1,0 +1,303 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs ONLY in the build container (it reads /root/reference, which does not exist on the GPU
+box).  It imports the reference's modules by file path, drives them on seeded synthetic inputs and
+stores inputs + expected outputs as small ``.npz`` files.  Nothing of the reference's source text is
+stored: the fixtures are data only.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+
+Absent third-party packages (funcy, vt_tools, numba, shapely) are replaced by *name-only* shims
+below so that the module-level imports succeed:
+  * ``vt_tools`` exports articulator NAME constants (used as dict keys only; the strings are the
+    ones the reference's YAML configs use, e.g. thesis_config/.../train_model_free.yaml:13-22);
+  * ``vt_tools.metrics.euclidean(u, v)`` / ``distance_matrix`` are ASSUMED to be the L2 norm of the
+    difference / pairwise L2 (vt_tools is an un-vendored, un-pinned dependency: requirements.txt:28-38).
+    => area_function fixtures are "parity pinned up to that assumption" (see DESIGN.md);
+  * ``numba.jit`` -> identity decorator, ``np.float`` -> float (removed from numpy>=1.24,
+    area_function.py:130 still uses it).
+shapely is absent: evenly_spaced_fx / intersect_semipolar_grid cannot run => no fixture (unpinned).
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- import plumbing
+def _shim(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def install_shims():
+    _shim("funcy", lmap=lambda f, *s: list(map(f, *s)), lfilter=lambda f, s: list(filter(f, s)))
+    vt = _shim(
+        "vt_tools",
+        LOWER_LIP="lower-lip", PHARYNX="pharynx", SOFT_PALATE_MIDLINE="soft-palate-midline",
+        TONGUE="tongue", UPPER_LIP="upper-lip", UPPER_INCISOR="upper-incisor",
+    )
+    vt.metrics = _shim(
+        "vt_tools.metrics",
+        euclidean=lambda u, v: float(np.sqrt(np.sum((np.asarray(u, dtype=np.float64) - np.asarray(v, dtype=np.float64)) ** 2))),
+        distance_matrix=lambda a, b: np.sqrt(((np.asarray(a)[:, None, :] - np.asarray(b)[None, :, :]) ** 2).sum(-1)),
+        p2cp_mean=None,
+    )
+    _shim("numba", jit=lambda *a, **k: (lambda f: f))
+    geom = _shim("shapely.geometry", LineString=None, Point=None)
+    _shim("shapely", geometry=geom)
+    if not hasattr(np, "float"):
+        np.float = float
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def sd_to_np(prefix, sd):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- model fixtures
+def masked_mean_loss(loss_fn, make_padding_mask, outputs, targets, lengths):
+    """train_phoneme_to_articulation.py:86-90, executed through the reference's own objects."""
+    loss = loss_fn(outputs, targets)
+    padding_mask = make_padding_mask(lengths)
+    bs, max_len, num_articulators, features = loss.shape
+    loss = loss.view(bs * max_len, num_articulators, features)
+    return loss[padding_mask.view(bs * max_len)].mean()
+
+
+def gen_artspeech(name, models, p2a_metrics, ed_metrics, helpers, settings, *, vocab, n_art, embed_dim,
+                  hidden, n_samples, B, T, lengths, seed, database="artspeech2"):
+    torch.manual_seed(seed)
+    model = models.ArtSpeech(vocab, n_art, embed_dim=embed_dim, hidden_size=hidden, n_samples=n_samples)
+    x = torch.randint(0, vocab, (B, T))
+    lengths = torch.tensor(lengths, dtype=torch.int)
+    tgt = torch.rand(B, T, n_art, 2, n_samples)
+    for i, l in enumerate(lengths):
+        x[i, l:] = 0
+        tgt[i, l:] = 0
+    out = model(x, lengths)
+    loss = masked_mean_loss(p2a_metrics.EuclideanDistance("none"), helpers.make_padding_mask, out, tgt, lengths)
+    loss.backward()
+    p2cp = ed_metrics.P2CPDistance(settings.DATASET_CONFIG[database])(out.detach(), tgt, lengths)
+    arrays = dict(
+        x=x.numpy(), lengths=lengths.numpy(), targets=tgt.numpy(), out=out.detach().numpy(),
+        loss=np.float32(loss.item()), p2cp_mm=np.float32(p2cp.item()),
+        cfg=np.array([vocab, n_art, embed_dim, hidden, n_samples], dtype=np.int64),
+    )
+    arrays.update(sd_to_np("w.", model.state_dict()))
+    arrays.update({"g." + k: p.grad.numpy() for k, p in model.named_parameters()})
+    save(name, **arrays)
+    gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters())))
+    return dict(out_sum=float(out.sum()), loss=float(loss), grad_norm=gn, p2cp_mm=float(p2cp),
+                out_0000_3=[float(v) for v in out[0, 0, 0, 0, :3]])
+
+
+def gen_simple(name, models, *, vocab, n_art, embed_dim, hidden, n_samples, B, T, seed):
+    torch.manual_seed(seed)
+    model = models.SimpleArtSpeech(vocab, n_art, embed_dim=embed_dim, hidden_size=hidden, num_samples=n_samples)
+    x = torch.randint(0, vocab, (B, T))
+    out = model(x, None)
+    dout = torch.randn_like(out)
+    (out * dout).sum().backward()
+    arrays = dict(x=x.numpy(), out=out.detach().numpy(), dout=dout.numpy(),
+                  cfg=np.array([vocab, n_art, embed_dim, hidden, n_samples], dtype=np.int64))
+    arrays.update(sd_to_np("w.", model.state_dict()))
+    arrays.update({"g." + k: p.grad.numpy() for k, p in model.named_parameters()})
+    save(name, **arrays)
+
+
+def gen_predictor(name, models, *, in_features, n_samples, rows, seed):
+    """ArticulatorPredictor alone (models.py:7-33): fwd + bwd on a (2, rows/2, in) input."""
+    torch.manual_seed(seed)
+    head = models.ArticulatorPredictor(in_features, n_samples)
+    # non-trivial LayerNorm affine so the fixture exercises gamma/beta
+    with torch.no_grad():
+        for i in (0, 3, 6):
+            head.linear[i].weight.uniform_(0.5, 1.5)
+            head.linear[i].bias.uniform_(-0.5, 0.5)
+    x = torch.randn(2, rows // 2, in_features, requires_grad=True)
+    out = head(x)
+    dout = torch.randn_like(out)
+    (out * dout).sum().backward()
+    arrays = dict(x=x.detach().numpy(), out=out.detach().numpy(), dout=dout.numpy(), dx=x.grad.numpy())
+    arrays.update(sd_to_np("w.", head.state_dict()))
+    arrays.update({"g." + k: p.grad.numpy() for k, p in head.named_parameters()})
+    save(name, **arrays)
+
+
+# ----------------------------------------------------------------------------- metric fixtures
+def gen_metrics(p2a_metrics, ed_metrics, root_metrics, settings):
+    torch.manual_seed(7)
+    B, T, A, N = 3, 9, 4, 50
+    out = torch.rand(B, T, A, 2, N, requires_grad=True)
+    tgt = torch.rand(B, T, A, 2, N)
+    lengths = torch.tensor([9, 6, 2], dtype=torch.int)
+    euc_none = p2a_metrics.EuclideanDistance("none")(out, tgt)
+    euc_mean = p2a_metrics.EuclideanDistance("mean")(out, tgt)
+    euc_mean.backward()
+    p2cp_none = p2a_metrics.MeanP2CPDistance("none")(out.detach().transpose(-1, -2), tgt.transpose(-1, -2))
+    p2cp_mean = p2a_metrics.MeanP2CPDistance("mean")(out.detach().transpose(-1, -2), tgt.transpose(-1, -2))
+    # N=10 <= 25: torch.cdist takes the direct (non-matmul) path
+    u10 = torch.rand(5, 7, 10, 2)
+    v12 = torch.rand(5, 7, 12, 2)
+    p2cp_small = p2a_metrics.MeanP2CPDistance("none")(u10, v12)
+    p2cp_mm = {db: ed_metrics.P2CPDistance(settings.DATASET_CONFIG[db])(out.detach(), tgt, lengths).item()
+               for db in ("artspeech2", "gottingen")}
+    x_corr, y_corr = root_metrics.pearsons_correlation(out.detach(), tgt)
+    save(
+        "metrics",
+        out=out.detach().numpy(), tgt=tgt.numpy(), lengths=lengths.numpy(),
+        euc_none=euc_none.detach().numpy(), euc_mean=np.float32(euc_mean.item()), euc_mean_grad=out.grad.numpy(),
+        p2cp_none=p2cp_none.numpy(), p2cp_mean=np.float32(p2cp_mean.item()),
+        u10=u10.numpy(), v12=v12.numpy(), p2cp_small=p2cp_small.numpy(),
+        p2cp_mm_artspeech2=np.float32(p2cp_mm["artspeech2"]), p2cp_mm_gottingen=np.float32(p2cp_mm["gottingen"]),
+        root_p2cp=root_metrics.p2cp_distance(out.detach(), tgt).numpy(),
+        root_euclid=root_metrics.euclidean_distance(out.detach(), tgt).numpy(),
+        x_corr=x_corr.numpy(), y_corr=y_corr.numpy(),
+    )
+
+
+def gen_tract_variables(tv):
+    """tract_variables.py:73-125 on random frames; inputs per articulator are (N, 2)."""
+    torch.manual_seed(11)
+    names = ["lower-lip", "pharynx", "soft-palate-midline", "tongue", "upper-incisor", "upper-lip"]  # sorted
+    F, N = 40, 50
+    frames = torch.rand(F, len(names), 2, N)  # model-output layout (A, 2, N) per frame
+    values = np.zeros((F, 4), dtype=np.float32)
+    poc1 = np.zeros((F, 4, 2), dtype=np.float32)
+    poc2 = np.zeros((F, 4, 2), dtype=np.float32)
+    tv_names = ["LA", "TTCD", "TBCD", "VEL"]
+    for f in range(F):
+        inputs = {art: t.T for art, t in zip(names, frames[f])}  # phoneme_to_articulation/__init__.py:253-255
+        res = tv.calculate_vocal_tract_variables(inputs)
+        assert [k for k, v in res.items() if v is not None] == tv_names
+        for j, k in enumerate(tv_names):
+            values[f, j] = res[k]["value"]
+            poc1[f, j] = res[k]["poc_1"].numpy()
+            poc2[f, j] = res[k]["poc_2"].numpy()
+    save("tract_variables", frames=frames.numpy(), values=values, poc1=poc1, poc2=poc2,
+         articulators=np.array(names), tv_names=np.array(tv_names))
+
+
+def gen_area_function(af):
+    rng = np.random.RandomState(3)
+    cases = {}
+    for i, nw in enumerate((100, 37, 2, 1)):
+        t = np.linspace(0.0, 1.0, nw)
+        internal = np.stack([t + 0.02 * rng.randn(nw), 0.3 + 0.05 * rng.randn(nw)], axis=1)
+        external = np.stack([t + 0.02 * rng.randn(nw), 0.6 + 0.05 * rng.randn(nw)], axis=1)
+        dists, fx = af.area_function(internal, external)
+        cases[f"int{i}"], cases[f"ext{i}"] = internal, external
+        cases[f"dists{i}"], cases[f"fx{i}"] = np.asarray(dists, dtype=np.float64), np.asarray(fx, dtype=np.float64)
+    # non-default alpha/beta
+    d, fx = af.area_function(cases["int0"], cases["ext0"], alpha=1.5, beta=1.3)
+    cases["dists0_ab"], cases["fx0_ab"] = np.asarray(d), np.asarray(fx)
+    grid = af.build_semipolar_grid(np.array([0.5, 0.45]), np.deg2rad(10.0), np.deg2rad(-5.0), 0.05, np.deg2rad(7.5), grid_res=50)
+    cases["grid"] = grid
+    cases["grid_args"] = np.array([0.5, 0.45, np.deg2rad(10.0), np.deg2rad(-5.0), 0.05, np.deg2rad(7.5), 50.0])
+    save("area_function", **cases)
+
+
+def gen_host(helpers, dataset):
+    """make_padding_mask (helpers.py:79-91) and the two collate fns (dataset.py:27-123)."""
+    torch.manual_seed(5)
+    lens = [5, 9, 3, 9]
+    A, N = 2, 6
+    batch = []
+    for i, l in enumerate(lens):
+        batch.append((
+            f"s{i}", torch.randint(1, 20, (l,)), torch.rand(l, A, 2, N), [f"p{i}_{j}" for j in range(l)],
+            torch.rand(l, 1, 2, N), torch.tensor([], dtype=torch.int), list(range(100 * i, 100 * i + l)),
+            (torch.rand(l) > 0.5).float(),
+        ))
+    c8 = dataset.pad_sequence_collate_fn(batch)
+    c12 = dataset.pad_sequence_transformer_collate_fn(batch)
+    arrays = {}
+    for i, item in enumerate(batch):
+        arrays[f"in{i}_tokens"], arrays[f"in{i}_targets"] = item[1].numpy(), item[2].numpy()
+        arrays[f"in{i}_refs"], arrays[f"in{i}_voicing"] = item[4].numpy(), item[7].numpy()
+    arrays.update(
+        ids=np.array(c8[0]), tokens=c8[1].numpy(), targets=c8[2].numpy(), lengths=c8[3].numpy(),
+        phonemes0=np.array(c8[4][0]), refs=c8[5].numpy(), frames0=np.array(c8[6][0]), voicing=c8[7].numpy(),
+        src_kpm=c12[8].numpy(), tgt_kpm=c12[9].numpy(), src_mask=c12[10].numpy(), tgt_mask=c12[11].numpy(),
+        t_tokens=c12[1].numpy(), t_lengths=c12[3].numpy(),
+        mask_9_6_2=helpers.make_padding_mask(torch.tensor([9, 6, 2])).numpy(),
+    )
+    save("host_collate", **arrays)
+
+
+def main():
+    install_shims()
+    sys.path.insert(0, REF)  # for `settings`, `helpers`
+    settings = _load("settings", "settings.py")
+    helpers = _load("helpers", "helpers.py")
+    models = _load("ref_ed_models", "phoneme_to_articulation/encoder_decoder/models.py")
+    # make `phoneme_to_articulation.metrics` importable without executing the package __init__
+    pkg = types.ModuleType("phoneme_to_articulation")
+    pkg.__path__ = [os.path.join(REF, "phoneme_to_articulation")]
+    pkg.InputLoaderMixin = object
+    sys.modules["phoneme_to_articulation"] = pkg
+    p2a_metrics = _load("phoneme_to_articulation.metrics", "phoneme_to_articulation/metrics.py")
+    edpkg = types.ModuleType("phoneme_to_articulation.encoder_decoder")
+    edpkg.__path__ = [os.path.join(REF, "phoneme_to_articulation/encoder_decoder")]
+    sys.modules["phoneme_to_articulation.encoder_decoder"] = edpkg
+    ed_metrics = _load("phoneme_to_articulation.encoder_decoder.metrics", "phoneme_to_articulation/encoder_decoder/metrics.py")
+    root_metrics = _load("ref_root_metrics", "metrics.py")
+    tv = _load("tract_variables", "tract_variables.py")
+    af = _load("ref_area_function", "area_function.py")
+    # dataset.py imports a few absent things at module level; give it empty shells
+    _shim("vt_shape_gen"); _shim("vt_shape_gen.helpers", load_articulator_array=None)
+    _shim("database_collector", DATABASE_COLLECTORS={})
+    _shim("phoneme_to_articulation.tail_clipper", TailClipper=None)
+    dataset = _load("ref_ed_dataset", "phoneme_to_articulation/encoder_decoder/dataset.py")
+
+    checks = {}
+    # C1 (SURVEY 8c recipe): ArtSpeech(45, 2), B=4 T=50 lengths [50,40,30,20]
+    checks["artspeech_c1"] = gen_artspeech(
+        "artspeech_c1", models, p2a_metrics, ed_metrics, helpers, settings,
+        vocab=45, n_art=2, embed_dim=64, hidden=128, n_samples=50, B=4, T=50, lengths=[50, 40, 30, 20], seed=0)
+    # small, odd sizes, ragged down to length 1, max(len) == T
+    checks["artspeech_small"] = gen_artspeech(
+        "artspeech_small", models, p2a_metrics, ed_metrics, helpers, settings,
+        vocab=13, n_art=3, embed_dim=16, hidden=32, n_samples=10, B=5, T=12, lengths=[12, 12, 9, 4, 1], seed=1)
+    # hidden 64 (the other width the reference's configs use), single utterance
+    checks["artspeech_h64"] = gen_artspeech(
+        "artspeech_h64", models, p2a_metrics, ed_metrics, helpers, settings,
+        vocab=9, n_art=1, embed_dim=24, hidden=64, n_samples=7, B=1, T=5, lengths=[5], seed=2)
+    gen_simple("simple_small", models, vocab=11, n_art=2, embed_dim=16, hidden=32, n_samples=10, B=3, T=7, seed=3)
+    gen_predictor("predictor_in128", models, in_features=128, n_samples=50, rows=70, seed=4)
+    gen_predictor("predictor_in32", models, in_features=32, n_samples=10, rows=18, seed=5)
+    gen_metrics(p2a_metrics, ed_metrics, root_metrics, settings)
+    gen_tract_variables(tv)
+    gen_area_function(af)
+    gen_host(helpers, dataset)
+    with open(os.path.join(OUT, "checksums.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
+    print(json.dumps(checks, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""Pin the CPU oracle against fixtures produced by the reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, split_wg
+from oracle import artspeech_oracle as O
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("name", ["artspeech_c1", "artspeech_small", "artspeech_h64"])
+def test_artspeech_fwd_bwd(name):
+    g = load_golden(name)
+    w, grads = split_wg(g)
+    n_art = int(g["cfg"][1])
+    out, cache = O.artspeech_fwd(w, g["x"], g["lengths"], n_art)
+    assert out.shape == g["out"].shape
+    assert np.abs(out - g["out"]).max() < 2e-6
+    loss, dout = O.masked_euclid_loss(out, g["targets"], g["lengths"])
+    assert abs(loss - g["loss"]) < 1e-6
+    og = O.artspeech_bwd(dout, cache, n_art)
+    assert set(og) == set(grads)
+    for k in grads:
+        assert relerr(og[k], grads[k]) < 2e-4, k
+    p2cp = O.p2cp_distance_mm(out, g["targets"], g["lengths"], 136 * 1.6176470518112)
+    assert abs(p2cp - g["p2cp_mm"]) / g["p2cp_mm"] < 2e-3  # reference's cdist uses the fp32 matmul expansion
+
+
+def test_artspeech_fp32_mode():
+    g = load_golden("artspeech_small")
+    w, _ = split_wg(g)
+    out, _ = O.artspeech_fwd(w, g["x"], g["lengths"], int(g["cfg"][1]), dtype=np.float32)
+    assert out.dtype == np.float32
+    assert np.abs(out - g["out"]).max() < 5e-6
+
+
+def test_padded_frames_are_not_zero():
+    # heads run on padded frames too (GRU output is zero there, LayerNorm/bias make outputs non-zero)
+    g = load_golden("artspeech_c1")
+    assert np.abs(g["out"][3, 25:]).min() > 0
+
+
+def test_simple_artspeech():
+    g = load_golden("simple_small")
+    w, grads = split_wg(g)
+    n_art = int(g["cfg"][1])
+    out, cache = O.simple_artspeech_fwd(w, g["x"], n_art)
+    assert np.abs(out - g["out"]).max() < 2e-6
+    og = O.simple_artspeech_bwd(g["dout"].astype(np.float64), cache, n_art)
+    for k in grads:
+        assert relerr(og[k], grads[k]) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["predictor_in128", "predictor_in32"])
+def test_predictor(name):
+    g = load_golden(name)
+    w, grads = split_wg(g)
+    p = {k: v.astype(np.float64) for k, v in w.items()}
+    out, cache = O.predictor_fwd(g["x"].astype(np.float64), p)
+    assert relerr(out, g["out"]) < 2e-6
+    dx, og = O.predictor_bwd(g["dout"].astype(np.float64), cache, p)
+    assert relerr(dx, g["dx"]) < 1e-5
+    for k in grads:
+        assert relerr(og[k], grads[k]) < 1e-5, k
+
+
+def test_metrics():
+    g = load_golden("metrics")
+    out, tgt = g["out"], g["tgt"]
+    assert relerr(O.euclidean_distance(out.astype(np.float64), tgt.astype(np.float64)), g["euc_none"]) < 1e-6
+    full = np.full(out.shape[0], out.shape[1])
+    loss, grad = O.masked_euclid_loss(out, tgt, full)
+    assert abs(loss - g["euc_mean"]) < 1e-6
+    assert relerr(grad, g["euc_mean_grad"]) < 1e-5
+    # direct formula vs the reference (which uses the fp32 matmul expansion for N=50): loose
+    assert relerr(O.p2cp_distance(out, tgt), g["p2cp_none"]) < 2e-3
+    assert relerr(O.p2cp_distance(out, tgt), g["root_p2cp"]) < 2e-3
+    # the fp32 expansion restated: closer to the reference than the direct formula is
+    mm = O.mean_p2cp_mm(np.swapaxes(out, -1, -2), np.swapaxes(tgt, -1, -2))
+    assert relerr(mm, g["p2cp_none"]) < 5e-4
+    # N, M <= 25: the reference takes the direct path -> tight
+    assert relerr(O.mean_p2cp(g["u10"], g["v12"]), g["p2cp_small"]) < 1e-6
+    for db, to_mm in (("artspeech2", 136 * 1.6176470518112), ("gottingen", 136 * 1.4117647409439)):
+        v = O.p2cp_distance_mm(out, tgt, g["lengths"], to_mm)
+        assert abs(v - g[f"p2cp_mm_{db}"]) / g[f"p2cp_mm_{db}"] < 2e-3
+    assert relerr(O.euclidean_distance_metric(out.astype(np.float64), tgt.astype(np.float64)), g["root_euclid"]) < 1e-6
+    xc, yc = O.pearsons_correlation(out.astype(np.float64), tgt.astype(np.float64))
+    assert np.abs(xc - g["x_corr"]).max() < 1e-5 and np.abs(yc - g["y_corr"]).max() < 1e-5
+
+
+def test_tract_variables():
+    g = load_golden("tract_variables")
+    arts = [str(a) for a in g["articulators"]]
+    for f in range(g["frames"].shape[0]):
+        vals, p1, p2, _ = O.tract_variables(g["frames"][f], arts, dtype=np.float32)
+        # TTCD (15x25) takes torch.cdist's direct path -> tight; LA/TBCD/VEL have a side > 25 and go
+        # through the reference's fp32 matmul expansion, whose error grows as 1/d for small d
+        assert abs(vals[1] - g["values"][f, 1]) < 1e-6
+        assert np.abs(vals - g["values"][f]).max() < 1e-4
+        # closest-point pairs must be the very same points (bit-exact coordinates)
+        assert np.array_equal(p1.astype(np.float32), g["poc1"][f])
+        assert np.array_equal(p2.astype(np.float32), g["poc2"][f])
+
+
+def test_area_function():
+    g = load_golden("area_function")
+    for i in range(4):
+        d, fx = O.area_function(g[f"int{i}"], g[f"ext{i}"])
+        assert d.shape == g[f"dists{i}"].shape
+        assert np.abs(d - g[f"dists{i}"]).max() < 1e-13 and np.abs(fx - g[f"fx{i}"]).max() < 1e-13
+    d, fx = O.area_function(g["int0"], g["ext0"], alpha=1.5, beta=1.3)
+    assert np.abs(d - g["dists0_ab"]).max() < 1e-13 and np.abs(fx - g["fx0_ab"]).max() < 1e-13
+    a = g["grid_args"]
+    grid = O.build_semipolar_grid(a[:2], a[2], a[3], a[4], a[5], int(a[6]))
+    assert grid.shape == g["grid"].shape and np.abs(grid - g["grid"]).max() < 1e-13
+
+
+def test_evenly_spaced_fx_properties():
+    # unpinned by the reference (shapely absent): check the defining properties instead
+    g = load_golden("area_function")
+    x, fx = g["dists0"], g["fx0"]
+    xfx = O.evenly_spaced_fx(x, fx, 200)
+    assert xfx.shape == (2, 200)
+    assert np.allclose(np.diff(xfx[0]), (x[-1] - x[0]) / 199)
+    assert xfx[1, 0] == fx[0] and abs(xfx[1, -1] - fx[-1]) < 1e-12
+
+
+def test_padding_mask():
+    g = load_golden("host_collate")
+    assert np.array_equal(O.make_padding_mask(np.array([9, 6, 2])), g["mask_9_6_2"])
