@@ -1,0 +1,63 @@
+"""Build recipe for libartspeech_hip.so (hipcc, gfx950 only).  Idempotent: sources newer than their
+object files are recompiled, then everything is linked in-tree next to this file."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libartspeech_hip.so")
+
+ARCH = "gfx950"
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+# per-file extra flags: metrics.hip keeps IEEE op-by-op arithmetic (arg-min pairs and the fp64 area
+# function must be bit-reproducible), so no fused multiply-add contraction there.
+SOURCES = {
+    "error.cpp": [],
+    "prof.hip": [],
+    "gemm_f32.hip": [],
+    "rowops.hip": [],
+    "gru.hip": [],
+    "metrics.hip": ["-ffp-contract=off"],
+    "artspeech.hip": [],
+}
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(s) > t for s in (src, *extra))
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "artspeech_hip.h"))
+    objs, relink = [], force
+    for name, extra in SOURCES.items():
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ, name.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, headers):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *COMMON, *extra, "-c", src, "-o", obj]
+            if name.endswith(".cpp"):
+                cmd = [hipcc, *COMMON, "-c", src, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or not os.path.exists(LIB):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

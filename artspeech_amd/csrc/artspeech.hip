@@ -1,0 +1,337 @@
+// Composite entry points: the flat parameter layout, the workspace carve and the launch sequences of
+// ArtSpeech / SimpleArtSpeech forward + backward and of the stacked ArticulatorPredictor heads.
+// This is the native "runtime" of the path: Python hands over pointers once per step; every kernel of
+// the step is enqueued from here on one HIP stream (graph-capturable: no allocation, no sync).
+//
+// Design notes (reference lines: encoder_decoder/models.py):
+//  * embedding (:135) + layer-0 input projection are folded into a [V][2][3H] row table (one tiny
+//    GEMM per step); the GRU kernel gathers table rows by token id, so neither the embedded sequence
+//    nor its projection is ever materialised.  Backward: per-token segment sum -> two tiny GEMMs.
+//  * every LayerNorm of the heads (:11,14,17) is applied affine-free (x_hat) and its gamma/beta are
+//    folded into the following Linear (W' = W.diag(gamma), b' = b + W.beta).  The first LayerNorm's
+//    x_hat is then shared by all A heads (same input row), and head GEMM 1 becomes ONE GEMM with
+//    N = A*256 columns.  The backward unfolds dW', db' into dW, dgamma, dbeta, db exactly.
+//  * heads are batched over A with strided-batched GEMMs on [rows][A][256] activations; the last GEMM
+//    writes sigmoid(.) straight into the (B, T, A, 2, N) output (:141-145).
+#include "rowops.h"
+
+namespace {
+
+constexpr int D = AS_HEAD_HIDDEN;
+
+struct Carve {
+    int64_t off = 0;
+    int64_t take(int64_t n) {
+        const int64_t o = off;
+        off += as_round_up(n, 64);
+        return o;
+    }
+};
+
+struct HeadWs {  // offsets in floats relative to the head workspace base
+    int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, colsum, total;
+};
+
+HeadWs head_ws(const as_dims& d, int64_t rows) {
+    const int64_t A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
+    Carve c;
+    HeadWs w;
+    w.xhat = c.take(rows * H);
+    w.rstd0 = c.take(rows);
+    w.w1f = c.take(A * D * H);
+    w.b1f = c.take(A * D);
+    w.w2f = c.take(A * D * D);
+    w.b2f = c.take(A * D);
+    w.w3f = c.take(A * O * D);
+    w.b3f = c.take(A * O);
+    w.r1 = c.take(rows * A * D);
+    w.r1hat = c.take(rows * A * D);
+    w.rstd1 = c.take(rows * A);
+    w.r2 = c.take(rows * A * D);
+    w.r2hat = c.take(rows * A * D);
+    w.rstd2 = c.take(rows * A);
+    w.dpre3 = c.take(rows * A * O);
+    w.dz2 = c.take(rows * A * D);
+    w.dz1 = c.take(rows * A * D);
+    w.dxhat = c.take(rows * H);
+    w.dw1f = c.take(A * D * H);
+    w.dw2f = c.take(A * D * D);
+    w.dw3f = c.take(A * O * D);
+    int64_t maxc = A * D;
+    if (6 * H > maxc) maxc = 6 * H;
+    if (A * O > maxc) maxc = A * O;
+    w.colsum = c.take((int64_t)128 * maxc);  // as_colsum_splits() <= 128 for any row count (also used with V rows)
+    w.total = c.off;
+    return w;
+}
+
+struct ModelWs {
+    int64_t tab0, y0, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
+};
+
+ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
+    const int64_t R = B * T, H = d.hidden, V = d.vocab;
+    Carve c;
+    ModelWs w{};
+    if (!d.simple) {
+        w.tab0 = c.take(V * 6 * H);
+        w.y0 = c.take(R * 2 * H);
+        w.g0 = c.take(R * 8 * H);
+        w.xp1 = c.take(R * 6 * H);
+        w.y1 = c.take(R * 2 * H);
+        w.g1 = c.take(R * 8 * H);
+        w.dy1 = c.take(R * 2 * H);
+        w.dgi1 = c.take(R * 6 * H);
+        w.dgh1 = c.take(R * 6 * H);
+        w.dy0 = c.take(R * 2 * H);
+        w.dgi0 = c.take(R * 6 * H);
+        w.dgh0 = c.take(R * 6 * H);
+        w.dtab0 = c.take(V * 6 * H);
+    } else {
+        w.tab0 = c.take(V * H);   // relu(Emb Wl^T + bl) per token
+        w.dtab0 = c.take(V * H);
+    }
+    w.lin = c.take(R * H);
+    w.head = c.take(head_ws(d, R).total);
+    w.total = c.off;
+    return w;
+}
+
+int check_dims(const as_dims* d, const char* who) {
+    AS_REQUIRE(d, AS_ERR_BAD_ARG, "%s: null dims", who);
+    AS_REQUIRE(d->vocab > 0 && d->n_art > 0 && d->embed > 0 && d->hidden > 0 && d->n_samp > 0, AS_ERR_BAD_ARG,
+               "%s: non-positive dimension (V=%d A=%d E=%d H=%d N=%d)", who, d->vocab, d->n_art, d->embed, d->hidden, d->n_samp);
+    AS_REQUIRE(d->hidden <= 512, AS_ERR_UNSUPPORTED, "%s: hidden size %d > 512", who, d->hidden);
+    if (!d->simple)
+        AS_REQUIRE(d->hidden == 32 || d->hidden == 64 || d->hidden == 128, AS_ERR_UNSUPPORTED,
+                   "%s: GRU hidden size %d not in {32, 64, 128}", who, d->hidden);
+    return 0;
+}
+
+// C = act(A . B^T + bias): both operands reduction-contiguous
+int gemm_nt(const float* A, long lda, const float* Bw, long ldb, float* C, long ldc, const float* bias, int M, int N, int K,
+            int act, hipStream_t st, int batch = 1, long ab = 0, long bb = 0, long cb = 0, long biasb = 0) {
+    as_gemm g{};
+    g.A = A; g.B = Bw; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.a_i = lda; g.a_k = 1; g.b_j = ldb; g.b_k = 1; g.ldc = ldc;
+    g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.bias_batch = biasb; g.act = act;
+    return as_gemm_f32(&g, st);
+}
+// C[M][N] = A[M][K] . B[K][N]   (input gradient: reduction over the rows of B)
+int gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
+            int batch = 1, long ab = 0, long bb = 0, long cb = 0) {
+    as_gemm g{};
+    g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.a_i = lda; g.a_k = 1; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
+    g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb;
+    return as_gemm_f32(&g, st);
+}
+// C[M][N] = A[K][M]^T . B[K][N]   (weight gradient: reduction over the rows of both)
+int gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
+            int batch = 1, long ab = 0, long bb = 0, long cb = 0, int kshift = 0, int kT = 0) {
+    as_gemm g{};
+    g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.a_i = 1; g.a_k = lda; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
+    g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.b_kshift = kshift; g.b_kT = kT;
+    return as_gemm_f32(&g, st);
+}
+
+int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const float* x, int64_t rows, float* out, float* ws,
+                  hipStream_t st) {
+    const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
+    const HeadWs w = head_ws(d, rows);
+    const int R = (int)rows;
+    AS_STEP("head.norm0", st, as_normalize_fwd(x, ws + w.xhat, ws + w.rstd0, rows, H, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w1, P + L.ln1_g, P + L.ln1_b, P + L.b1, ws + w.w1f, ws + w.b1f, A, D, H, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w2, P + L.ln2_g, P + L.ln2_b, P + L.b2, ws + w.w2f, ws + w.b2f, A, D, D, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st));
+    // GEMM 1: all heads at once (shared x_hat): r1 [rows][A*D]
+    AS_STEP("head.gemm1", st, gemm_nt(ws + w.xhat, H, ws + w.w1f, H, ws + w.r1, (long)A * D, ws + w.b1f, R, A * D, H, 1, st));
+    AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st));
+    // GEMM 2: batched over heads on [rows][A][D]
+    AS_STEP("head.gemm2", st, gemm_nt(ws + w.r1hat, (long)A * D, ws + w.w2f, D, ws + w.r2, (long)A * D, ws + w.b2f, R, D, D, 1, st, A, D,
+                   (long)D * D, D, D));
+    AS_STEP("head.norm2", st, as_normalize_fwd(ws + w.r2, ws + w.r2hat, ws + w.rstd2, rows * A, D, st));
+    // GEMM 3: sigmoid epilogue writes out[rows][A][2][N]
+    AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, (long)A * D, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D, (long)O * D, O,
+                   O));
+    return 0;
+}
+
+// relu_src: optional [rows][H] activation whose ReLU produced x (its mask is fused into the last step)
+int head_bwd_impl(const as_dims& d, const as_layout& L, const float* P, const float* out, const float* dout, int64_t rows,
+                  float* dx, const float* relu_src, float* G, float* ws, hipStream_t st) {
+    const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
+    const HeadWs w = head_ws(d, rows);
+    const int R = (int)rows;
+    const long AD = (long)A * D, AO = (long)A * O;
+    float* part = ws + w.colsum;
+    AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
+    // layer 3
+    AS_STEP("headb.colsum", st, as_colsum(ws + w.dpre3, rows, (int)AO, AO, G + L.b3, part, st));
+    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, A, O, D, (long)O * D));
+    AS_STEP("headb.dx3", st, gemm_nn(ws + w.dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
+    AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
+    // layer 2
+    AS_STEP("headb.colsum", st, as_colsum(ws + w.dz2, rows, (int)AD, AD, G + L.b2, part, st));
+    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, A, D, D, (long)D * D));
+    AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
+    AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
+    // layer 1 (all heads in one GEMM each way)
+    AS_STEP("headb.colsum", st, as_colsum(ws + w.dz1, rows, (int)AD, AD, G + L.b1, part, st));
+    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st));
+    AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st));
+    AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));
+    // unfold the LayerNorm affines
+    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw3f, G + L.b3, P + L.w3, P + L.ln3_g, P + L.ln3_b, G + L.w3, G + L.ln3_g, G + L.ln3_b, A, O, D, st));
+    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw2f, G + L.b2, P + L.w2, P + L.ln2_g, P + L.ln2_b, G + L.w2, G + L.ln2_g, G + L.ln2_b, A, D, D, st));
+    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw1f, G + L.b1, P + L.w1, P + L.ln1_g, P + L.ln1_b, G + L.w1, G + L.ln1_g, G + L.ln1_b, A, D, H, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int as_artspeech_layout(const as_dims* d, as_layout* out) {
+    AS_TRY(check_dims(d, "as_artspeech_layout"));
+    AS_REQUIRE(out, AS_ERR_BAD_ARG, "as_artspeech_layout: null out");
+    const int64_t V = d->vocab, A = d->n_art, E = d->embed, H = d->hidden, N = d->n_samp;
+    Carve c;
+    as_layout L{};
+    L.embedding = c.take(V * E);
+    if (!d->simple) {
+        const int64_t in[2] = {E, 2 * H};
+        for (int l = 0; l < 2; ++l) {
+            L.w_ih[l] = c.take(2 * 3 * H * in[l]);
+            L.b_ih[l] = c.take(2 * 3 * H);
+            L.w_hh[l] = c.take(2 * 3 * H * H);
+            L.b_hh[l] = c.take(2 * 3 * H);
+        }
+        L.lin_w = c.take(H * 2 * H);
+    } else {
+        for (int l = 0; l < 2; ++l) L.w_ih[l] = L.b_ih[l] = L.w_hh[l] = L.b_hh[l] = -1;
+        L.lin_w = c.take(H * E);
+    }
+    L.lin_b = c.take(H);
+    L.ln1_g = c.take(A * H);
+    L.ln1_b = c.take(A * H);
+    L.w1 = c.take(A * D * H);
+    L.b1 = c.take(A * D);
+    L.ln2_g = c.take(A * D);
+    L.ln2_b = c.take(A * D);
+    L.w2 = c.take(A * D * D);
+    L.b2 = c.take(A * D);
+    L.ln3_g = c.take(A * D);
+    L.ln3_b = c.take(A * D);
+    L.w3 = c.take(A * 2 * N * D);
+    L.b3 = c.take(A * 2 * N);
+    L.total = c.off;
+    *out = L;
+    return 0;
+}
+
+extern "C" int64_t as_head_workspace_floats(const as_dims* d, int64_t rows) {
+    if (check_dims(d, "as_head_workspace_floats") != 0 || rows <= 0) return -1;
+    return head_ws(*d, rows).total;
+}
+
+extern "C" int64_t as_artspeech_workspace_floats(const as_dims* d, int32_t B, int32_t T) {
+    if (check_dims(d, "as_artspeech_workspace_floats") != 0 || B <= 0 || T <= 0) return -1;
+    return model_ws(*d, B, T).total;
+}
+
+extern "C" int as_head_fwd(const as_dims* d, const as_layout* lay, const float* params, const float* x, int64_t rows,
+                           float* out, float* ws, int32_t train, void* stream) {
+    (void)train;  // the forward keeps its activations in ws either way
+    AS_TRY(check_dims(d, "as_head_fwd"));
+    AS_REQUIRE(lay && params && x && out && ws && rows > 0 && rows < (1LL << 31), AS_ERR_BAD_ARG, "as_head_fwd: bad argument");
+    return head_fwd_impl(*d, *lay, params, x, rows, out, ws, (hipStream_t)stream);
+}
+
+extern "C" int as_head_bwd(const as_dims* d, const as_layout* lay, const float* params, const float* out, const float* dout,
+                           int64_t rows, float* dx, float* grads, float* ws, void* stream) {
+    AS_TRY(check_dims(d, "as_head_bwd"));
+    AS_REQUIRE(lay && params && out && dout && dx && grads && ws && rows > 0 && rows < (1LL << 31), AS_ERR_BAD_ARG,
+               "as_head_bwd: bad argument");
+    return head_bwd_impl(*d, *lay, params, out, dout, rows, dx, nullptr, grads, ws, (hipStream_t)stream);
+}
+
+extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
+                                const int32_t* lengths, int32_t B, int32_t T, float* out, float* ws, int32_t train,
+                                void* stream) {
+    AS_TRY(check_dims(d, "as_artspeech_fwd"));
+    AS_REQUIRE(P && tokens && out && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG, "as_artspeech_fwd: bad argument");
+    AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_fwd: lengths required for the GRU model");
+    AS_REQUIRE((int64_t)B * T < (1LL << 31), AS_ERR_BAD_ARG, "as_artspeech_fwd: B*T too large");
+    hipStream_t st = (hipStream_t)stream;
+    as_layout L;
+    AS_TRY(as_artspeech_layout(d, &L));
+    const ModelWs w = model_ws(*d, B, T);
+    const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
+    if (!d->simple) {
+        // token table of layer-0 input projections, both directions: [V][2][3H]
+        AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));
+        AS_STEP("gru.fwd_l0", st, as_gru_bidir_fwd(ws + w.tab0, tokens, tok_stride, P + L.w_hh[0], P + L.b_hh[0], lengths, B, T, H, ws + w.y0,
+                                train ? ws + w.g0 : nullptr, st));
+        AS_STEP("gru.xproj1", st, gemm_nt(ws + w.y0, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
+        AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
+                                train ? ws + w.g1 : nullptr, st));
+        AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
+    } else {
+        AS_TRY(gemm_nt(P + L.embedding, E, P + L.lin_w, E, ws + w.tab0, H, P + L.lin_b, V, H, E, 1, st));
+        AS_TRY(as_gather_rows(ws + w.tab0, tokens, tok_stride, T, R, H, ws + w.lin, st));
+    }
+    return head_fwd_impl(*d, L, P, ws + w.lin, R, out, ws + w.head, st);
+}
+
+extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
+                                const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout, float* G,
+                                float* ws, void* stream) {
+    AS_TRY(check_dims(d, "as_artspeech_bwd"));
+    AS_REQUIRE(P && tokens && out && dout && G && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG,
+               "as_artspeech_bwd: bad argument");
+    AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_bwd: lengths required for the GRU model");
+    hipStream_t st = (hipStream_t)stream;
+    as_layout L;
+    AS_TRY(as_artspeech_layout(d, &L));
+    const ModelWs w = model_ws(*d, B, T);
+    const HeadWs hw = head_ws(*d, (int64_t)B * T);
+    const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
+    float* part = ws + w.head + hw.colsum;
+    float* dzlin = ws + w.head + hw.dxhat;  // reused: d(trunk pre-activation) [R][H]
+    // heads (+ the trunk ReLU mask fused into the last normalize-backward)
+    AS_TRY(head_bwd_impl(*d, L, P, out, dout, R, dzlin, ws + w.lin, G, ws + w.head, st));
+    if (d->simple) {
+        // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
+        AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st));
+        AS_TRY(as_colsum(ws + w.dtab0, V, H, H, G + L.lin_b, part, st));
+        AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st));
+        AS_TRY(gemm_nn(ws + w.dtab0, H, P + L.lin_w, E, G + L.embedding, E, V, E, H, st));
+        return 0;
+    }
+    // trunk Linear(2H -> H)
+    AS_STEP("trunkb.colsum", st, as_colsum(dzlin, R, H, H, G + L.lin_b, part, st));
+    AS_STEP("trunkb.dw", st, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, st));
+    AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
+    // GRU layer 1
+    AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
+    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgi1, R, 6 * H, 6 * H, G + L.b_ih[1], part, st));
+    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgh1, R, 6 * H, 6 * H, G + L.b_hh[1], part, st));
+    AS_STEP("grub.dw_ih1", st, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, st));
+    for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
+        AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
+                       3 * H, H, R, st, 1, 0, 0, 0, dir ? 1 : -1, T));
+    AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
+    // GRU layer 0
+    AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
+    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgh0, R, 6 * H, 6 * H, G + L.b_hh[0], part, st));
+    for (int dir = 0; dir < 2; ++dir)
+        AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
+                       3 * H, H, R, st, 1, 0, 0, 0, dir ? 1 : -1, T));
+    // embedding + layer-0 input projection through the token table
+    AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st));
+    AS_STEP("grub.colsum", st, as_colsum(ws + w.dtab0, V, 6 * H, 6 * H, G + L.b_ih[0], part, st));
+    AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st));
+    AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st));
+    return 0;
+}

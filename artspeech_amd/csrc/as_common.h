@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libartspeech_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "artspeech_hip.h"
+
+#define AS_WAVE 64
+
+void as_set_error(const char* fmt, ...);
+
+#define AS_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            as_set_error(__VA_ARGS__);         \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// launch check: kernels are enqueued, never synchronised
+#define AS_LAUNCH_CHECK(name)                                                  \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            as_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                   \
+        }                                                                      \
+    } while (0)
+
+#define AS_TRY(expr)            \
+    do {                        \
+        int r__ = (expr);       \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+// optional per-phase timing (prof.hip); a no-op unless as_profile_enable(1)
+struct AsProfScope {
+    AsProfScope(const char* name, hipStream_t st);
+    ~AsProfScope();
+    const char* name_; hipStream_t st_; void* a_; void* b_;
+};
+#define AS_PROF_CAT2(a, b) a##b
+#define AS_PROF_CAT(a, b) AS_PROF_CAT2(a, b)
+#define AS_PROF(name, st) AsProfScope AS_PROF_CAT(as_prof_scope_, __LINE__)(name, st)
+// one named, timed launch sequence
+#define AS_STEP(name, st, expr) \
+    do {                        \
+        AS_PROF(name, st);      \
+        AS_TRY(expr);           \
+    } while (0)
+
+static inline int64_t as_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int as_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float as_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double as_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float as_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via one exp: |abs err| ~ 1e-7, no overflow (exp(+inf) -> inf -> 2/inf = 0 -> 1)
+__device__ __forceinline__ float as_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }

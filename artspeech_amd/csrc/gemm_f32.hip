@@ -1,0 +1,236 @@
+// Strided-batched fp32 GEMM on the CDNA4 f32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32, a
+// k-ordered fmaf chain, 64 FLOP/clk/SIMD).  One kernel template serves the three shapes the training
+// step needs -- forward linears (both operands reduction-contiguous), input gradients and weight
+// gradients (reduction index strided) -- by choosing the LDS image per operand:
+//   reduction-contiguous operand  -> image [i][BK+1]  (odd row stride: conflict-free ds_read_b32 column reads)
+//   output-contiguous operand     -> image [k][BI]    (lanes 0-31 / 32-63 read two consecutive k rows)
+// so that a lane's MFMA operand (A[i = lane&31][k = lane>>5]) is always one conflict-free ds_read_b32.
+// 256 threads = 4 waves in a 2x2 arrangement; global->register->LDS staging is software pipelined
+// (loads of tile t+1 in flight while the matrix core works on tile t), one barrier per K tile.
+#include "as_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+
+struct GemmK {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long a_i, a_k, b_j, b_k, ldc;
+    long a_batch, b_batch, c_batch, bias_batch;
+    int act, accumulate, b_kshift, b_kT;
+    int a_vec, b_vec;
+};
+
+template <int BI, bool KC> struct Img { static constexpr int size = KC ? BI * (BK + 1) : BK * BI; };
+
+// global -> registers for one operand tile.  I = extent of the output index, K = extent of the reduction.
+template <int BI, bool KC>
+__device__ __forceinline__ void tile_load(float4 (&r)[BI / 32], const float* __restrict__ p, long s_i, long s_k,
+                                          int i0, int k0, int I, int K, bool vec, int kshift, int kT, int tid) {
+    constexpr int P = BI / 32;
+    if constexpr (KC) {
+        const int kq = tid & 7, row0 = tid >> 3;
+        const int k = k0 + kq * 4;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const int i = i0 + row0 + 32 * pp;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < I) {
+                const float* q = p + (long)i * s_i + k;
+                if (vec && k + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (k < K) v.x = q[0];
+                    if (k + 1 < K) v.y = q[1];
+                    if (k + 2 < K) v.z = q[2];
+                    if (k + 3 < K) v.w = q[3];
+                }
+            }
+            r[pp] = v;
+        }
+    } else {
+        constexpr int V4 = BI / 4;          // float4 per k row
+        constexpr int RP = 256 / V4;        // k rows per pass
+        const int iq = tid % V4, kr0 = tid / V4;
+        const int i = i0 + iq * 4;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const int k = k0 + kr0 + RP * pp;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = k < K;
+            long ks = k;
+            if (kT > 0) {
+                const int t = k % kT + kshift;
+                ok = ok && t >= 0 && t < kT;
+                ks = (long)k + kshift;
+            }
+            if (ok) {
+                const float* q = p + ks * s_k + i;
+                if (vec && i + 3 < I) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (i < I) v.x = q[0];
+                    if (i + 1 < I) v.y = q[1];
+                    if (i + 2 < I) v.z = q[2];
+                    if (i + 3 < I) v.w = q[3];
+                }
+            }
+            r[pp] = v;
+        }
+    }
+}
+
+template <int BI, bool KC>
+__device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (&r)[BI / 32], int tid) {
+    constexpr int P = BI / 32;
+    if constexpr (KC) {
+        const int kq = tid & 7, row0 = tid >> 3;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            float* d = s + (row0 + 32 * pp) * (BK + 1) + kq * 4;
+            d[0] = r[pp].x; d[1] = r[pp].y; d[2] = r[pp].z; d[3] = r[pp].w;
+        }
+    } else {
+        constexpr int V4 = BI / 4;
+        constexpr int RP = 256 / V4;
+        const int iq = tid % V4, kr0 = tid / V4;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+            *reinterpret_cast<float4*>(s + (kr0 + RP * pp) * BI + iq * 4) = r[pp];
+    }
+}
+
+template <int BI, bool KC>
+__device__ __forceinline__ float frag(const float* __restrict__ s, int i, int k) {
+    return KC ? s[i * (BK + 1) + k] : s[k * BI + i];
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float sA[2][Img<BM, A_KC>::size];
+    __shared__ __attribute__((aligned(16))) float sB[2][Img<BN, B_KC>::size];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int tm_idx = blockIdx.x % tiles_m, tn_idx = blockIdx.x / tiles_m;
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+    const int bz = blockIdx.z;
+    const float* A = g.A + (long)bz * g.a_batch;
+    const float* B = g.B + (long)bz * g.b_batch;
+    float* C = g.C + (long)bz * g.c_batch;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    const int nk = (g.K + BK - 1) / BK;
+    tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, 0, g.M, g.K, g.a_vec, 0, 0, tid);
+    tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, 0, g.N, g.K, g.b_vec, g.b_kshift, g.b_kT, tid);
+    tile_store<BM, A_KC>(sA[0], ra, tid);
+    tile_store<BN, B_KC>(sB[0], rb, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, (kt + 1) * BK, g.M, g.K, g.a_vec, 0, 0, tid);
+            tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, (kt + 1) * BK, g.N, g.K, g.b_vec, g.b_kshift, g.b_kT, tid);
+        }
+        const float* a_s = sA[cur];
+        const float* b_s = sB[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = frag<BM, A_KC>(a_s, wm * WM + i * 32 + l31, kk + lh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = frag<BN, B_KC>(b_s, wn * WN + j * 32 + l31, kk + lh);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            tile_store<BM, A_KC>(sA[cur ^ 1], ra, tid);
+            tile_store<BN, B_KC>(sB[cur ^ 1], rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float* bias = g.bias ? g.bias + (long)bz * g.bias_batch : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bj;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                else if (g.act == 2) v = as_sigmoid(v);
+                float* c = C + (long)row * g.ldc + col;
+                if (g.accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
+    dim3 grid(as_cdiv(k.M, BM) * as_cdiv(k.N, BN), 1, batch), block(256);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, k);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, k);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, k);
+    AS_LAUNCH_CHECK("as_gemm_f32");
+    return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
+    AS_REQUIRE(g && g->A && g->B && g->C, AS_ERR_BAD_ARG, "as_gemm_f32: null pointer");
+    AS_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0 && g->batch > 0, AS_ERR_BAD_ARG,
+               "as_gemm_f32: non-positive size M=%d N=%d K=%d batch=%d", g->M, g->N, g->K, g->batch);
+    AS_REQUIRE((g->a_i == 1) != (g->a_k == 1) || (g->a_i == 1 && g->a_k == 1 && (g->M == 1 || g->K == 1)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of a_i/a_k must be 1 (a_i=%ld a_k=%ld)", (long)g->a_i, (long)g->a_k);
+    AS_REQUIRE((g->b_j == 1) != (g->b_k == 1) || (g->b_j == 1 && g->b_k == 1 && (g->N == 1 || g->K == 1)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of b_j/b_k must be 1 (b_j=%ld b_k=%ld)", (long)g->b_j, (long)g->b_k);
+    AS_REQUIRE(g->act >= 0 && g->act <= 2, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
+    const bool a_kc = g->a_k == 1, b_kc = g->b_k == 1;
+    AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
+    GemmK k;
+    k.A = g->A; k.B = g->B; k.C = g->C; k.bias = g->bias;
+    k.M = g->M; k.N = g->N; k.K = g->K;
+    k.a_i = g->a_i; k.a_k = g->a_k; k.b_j = g->b_j; k.b_k = g->b_k; k.ldc = g->ldc;
+    k.a_batch = g->a_batch; k.b_batch = g->b_batch; k.c_batch = g->c_batch; k.bias_batch = g->bias_batch;
+    k.act = g->act; k.accumulate = g->accumulate; k.b_kshift = g->b_kshift; k.b_kT = g->b_kT;
+    const long a_ld = a_kc ? g->a_i : g->a_k, b_ld = b_kc ? g->b_j : g->b_k;
+    k.a_vec = aligned16(g->A) && a_ld % 4 == 0 && g->a_batch % 4 == 0;
+    k.b_vec = aligned16(g->B) && b_ld % 4 == 0 && g->b_batch % 4 == 0;
+    hipStream_t st = (hipStream_t)stream;
+    // 128x128 tiles once they fill the chip, else 64x64 for more workgroups
+    const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
+    if (big >= 256 && g->N >= 96) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
+    return launch<64, 64>(k, g->batch, a_kc, b_kc, st);
+}

@@ -1,0 +1,350 @@
+// Loss / metric / DSP kernels of the hot path -- all HBM-bound streaming or tiny-tile work:
+//   EuclideanDistance (+ fused length-masked mean and its gradient), MeanP2CPDistance tiles,
+//   P2CPDistance utterance means, tract variables (min pairwise distance + closest pair) and the
+//   vocal-tract area function (fp64).  One wave per tile/frame where a tile is small; coalesced
+//   4-byte lanes over the (.., 2, N) contour rows (N = 50 floats = 200 B rows are only 8-byte aligned).
+#include "as_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- EuclideanDistance ("none")
+__global__ __launch_bounds__(256) void euclid_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                         long points, int N, float* __restrict__ dist) {
+    const long stride = (long)gridDim.x * 256;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < points; p += stride) {
+        const long row = p / N;  // (frame, articulator)
+        const int n = (int)(p - row * N);
+        const long base = row * 2 * N + n;
+        const float dx = out[base] - tgt[base], dy = out[base + N] - tgt[base + N];
+        dist[p] = sqrtf(dx * dx + dy * dy);
+    }
+}
+__global__ __launch_bounds__(256) void euclid_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                         const float* __restrict__ ddist, long points, int N,
+                                                         float* __restrict__ dout) {
+    const long stride = (long)gridDim.x * 256;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < points; p += stride) {
+        const long row = p / N;
+        const int n = (int)(p - row * N);
+        const long base = row * 2 * N + n;
+        const float dx = out[base] - tgt[base], dy = out[base + N] - tgt[base + N];
+        const float g = ddist[p] / sqrtf(dx * dx + dy * dy);  // NaN at zero distance, as torch autograd
+        dout[base] = dx * g;
+        dout[base + N] = dy * g;
+    }
+}
+
+// ---------------------------------------------------------------- fused masked mean + gradient
+constexpr int LOSS_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void euclid_masked_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                            long tgt_T, const int* __restrict__ lengths, int T, int A,
+                                                            int N, long points, float scale, float* __restrict__ dout,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[4];
+    const long stride = (long)gridDim.x * 256;
+    const int AN = A * N;
+    float s = 0.f;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < points; p += stride) {
+        const long frame = p / AN;
+        const int rem = (int)(p - frame * AN);
+        const int a = rem / N, n = rem - a * N;
+        const long b = frame / T;
+        const int t = (int)(frame - b * T);
+        const long ob = (frame * A + a) * 2 * N + n;
+        if (t < lengths[b]) {
+            const long tb = ((b * tgt_T + t) * A + a) * 2 * N + n;
+            const float dx = out[ob] - tgt[tb], dy = out[ob + N] - tgt[tb + N];
+            const float d = sqrtf(dx * dx + dy * dy);
+            s += d;
+            if (dout) {
+                const float g = scale / d;
+                dout[ob] = dx * g;
+                dout[ob + N] = dy * g;
+            }
+        } else if (dout) {
+            dout[ob] = 0.f;
+            dout[ob + N] = 0.f;
+        }
+    }
+    s = as_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ partial, int n, float scale,
+                                                         float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = as_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+// ---------------------------------------------------------------- MeanP2CPDistance
+// one wave per (u, v) tile: both point sets staged in LDS; lane i scans all v for u_i (row minima),
+// lane j scans all u for v_j (column minima).  min over squared distances, sqrt once (monotone).
+constexpr int P2CP_MAXPTS = 256;
+
+__global__ __launch_bounds__(256) void p2cp_kernel(const float* __restrict__ u, long u_tile, long u_pt, long u_xy, int nu,
+                                                   const float* __restrict__ v, long v_tile, long v_pt, long v_xy, int nv,
+                                                   long tiles, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    float* ux = smem + (long)wave * 2 * (nu + nv);
+    float* uy = ux + nu;
+    float* vx = uy + nu;
+    float* vy = vx + nv;
+    if (tile < tiles) {
+        const float* up = u + tile * u_tile;
+        const float* vp = v + tile * v_tile;
+        for (int i = lane; i < nu; i += 64) { ux[i] = up[i * u_pt]; uy[i] = up[i * u_pt + u_xy]; }
+        for (int i = lane; i < nv; i += 64) { vx[i] = vp[i * v_pt]; vy[i] = vp[i * v_pt + v_xy]; }
+    }
+    __syncthreads();
+    if (tile >= tiles) return;
+    float su = 0.f, sv = 0.f;
+    for (int i = lane; i < nu; i += 64) {
+        const float px = ux[i], py = uy[i];
+        float m = INFINITY;
+        for (int j = 0; j < nv; ++j) {
+            const float dx = px - vx[j], dy = py - vy[j];
+            m = fminf(m, dx * dx + dy * dy);
+        }
+        su += sqrtf(m);
+    }
+    for (int j = lane; j < nv; j += 64) {
+        const float px = vx[j], py = vy[j];
+        float m = INFINITY;
+        for (int i = 0; i < nu; ++i) {
+            const float dx = ux[i] - px, dy = uy[i] - py;
+            m = fminf(m, dx * dx + dy * dy);
+        }
+        sv += sqrtf(m);
+    }
+    su = as_wave_sum(su);
+    sv = as_wave_sum(sv);
+    if (lane == 0) out[tile] = (su / nu + sv / nv) * 0.5f;
+}
+
+// P2CPDistance: mean_b( mean_{t<len_b, a} p2cp[b][t][a] * to_mm ); one block, wave per utterance
+__global__ __launch_bounds__(256) void p2cp_utt_mean_kernel(const float* __restrict__ p2cp, const int* __restrict__ lengths,
+                                                            int B, int T, int A, float to_mm, float* __restrict__ result) {
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const int n = lengths[b] * A;
+        const float* p = p2cp + (long)b * T * A;
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += p[i] * to_mm;
+        s = as_wave_sum(s);
+        acc += s / n;
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) result[0] = ((red[0] + red[1]) + (red[2] + red[3])) / B;
+}
+
+// ---------------------------------------------------------------- tract variables
+// one wave per (frame, variable).  Lane j owns arr2 point j and scans arr1 in order keeping the FIRST
+// minimum (strict <), exactly torch's min(dim=0); then the wave takes the first minimum over j.
+// Distances use un-contracted fp32 ops (mul, mul, add, sqrt) so that they are bit-identical to the
+// element-wise formula and the arg-min pairs are reproducible.
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ contours, long frames, int A, int N,
+                                                 const int* __restrict__ spec, int n_tv, float* __restrict__ values,
+                                                 float* __restrict__ poc1, float* __restrict__ poc2, int* __restrict__ idx) {
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= frames * n_tv) return;
+    const long f = item / n_tv;
+    const int v = (int)(item - f * n_tv);
+    const int* sp = spec + v * 9;
+    const float* fr = contours + f * (long)A * 2 * N;
+    const int c1 = sp[0], s1 = sp[1], n1 = sp[2] - sp[1];
+    const int c2a = sp[3], s2a = sp[4], n2a = sp[5] - sp[4];
+    const int c2b = sp[6], s2b = sp[7], n2b = c2b >= 0 ? sp[8] - sp[7] : 0;
+    const int n2 = n2a + n2b;
+    const float* x1 = fr + (long)c1 * 2 * N + s1;
+    float best = INFINITY;
+    int bi = 0, bj = 0x7fffffff;
+    float bx2 = 0.f, by2 = 0.f;
+    for (int j = lane; j < n2; j += 64) {
+        const float* p2 = j < n2a ? fr + (long)c2a * 2 * N + s2a + j : fr + (long)c2b * 2 * N + s2b + (j - n2a);
+        const float qx = p2[0], qy = p2[N];
+        float m = INFINITY;
+        int mi = 0;
+        for (int i = 0; i < n1; ++i) {
+            const float dx = __fsub_rn(x1[i], qx), dy = __fsub_rn(x1[N + i], qy);
+            // correctly rounded fp32 sqrt via fp64 (v_sqrt_f32 alone is 1 ulp): 53 >= 2*24+2 bits, so the
+            // double rounding is exact and d is bit-identical to an IEEE sqrtf on the host
+            const float d = (float)__dsqrt_rn((double)__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            if (d < m) { m = d; mi = i; }
+        }
+        if (m < best) { best = m; bi = mi; bj = j; bx2 = qx; by2 = qy; }  // j ascending per lane: first min kept
+    }
+    // wave arg-min with smallest-j tie break
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64), oj = __shfl_xor(bj, o, 64);
+        const float ox = __shfl_xor(bx2, o, 64), oy = __shfl_xor(by2, o, 64);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bi = oi; bj = oj; bx2 = ox; by2 = oy; }
+    }
+    if (lane == 0) {
+        values[item] = best;
+        poc1[item * 2] = x1[bi];
+        poc1[item * 2 + 1] = x1[N + bi];
+        poc2[item * 2] = bx2;
+        poc2[item * 2 + 1] = by2;
+        if (idx) { idx[item * 2] = bi; idx[item * 2 + 1] = bj; }
+    }
+}
+
+// ---------------------------------------------------------------- area function (fp64)
+// one wave per frame.  Lanes compute mid points, radii and fx in parallel; the arc length is the
+// SEQUENTIAL running sum of the reference's loop (lane 0), so dists is bit-identical to a serial
+// fp64 evaluation.  un-contracted arithmetic throughout.
+__global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi, const double* __restrict__ we,
+                                                   long frame_stride, long pt_stride, long xy_stride, long frames, int n,
+                                                   double alpha, double beta, int beta_is_two, double* __restrict__ dists,
+                                                   double* __restrict__ fx) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + wave;
+    double* mx = dsm + (long)wave * 2 * n;
+    double* my = mx + n;
+    if (f < frames) {
+        const double* a = wi + f * frame_stride;
+        const double* b = we + f * frame_stride;
+        for (int i = lane; i < n; i += 64) {
+            const double ax = a[i * pt_stride], ay = a[i * pt_stride + xy_stride];
+            const double bx = b[i * pt_stride], by = b[i * pt_stride + xy_stride];
+            mx[i] = __dadd_rn(fmin(ax, bx), __ddiv_rn(fabs(__dsub_rn(ax, bx)), 2.0));
+            my[i] = __dadd_rn(fmin(ay, by), __ddiv_rn(fabs(__dsub_rn(ay, by)), 2.0));
+            const double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by);
+            const double r = __ddiv_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), 2.0);
+            fx[f * n + i] = __dmul_rn(alpha, beta_is_two ? __dmul_rn(r, r) : pow(r, beta));
+        }
+    }
+    __syncthreads();
+    if (f >= frames) return;
+    // segment lengths in parallel (kept in place of my[] after use), then the ordered running sum
+    double seg[4];  // n <= 256
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = lane + 64 * c;
+        seg[c] = 0.0;
+        if (i >= 1 && i < n) {
+            const double dx = __dsub_rn(mx[i], mx[i - 1]), dy = __dsub_rn(my[i], my[i - 1]);
+            seg[c] = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = lane + 64 * c;
+        if (i < n) mx[i] = seg[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double d = 0.0;
+        dists[f * n] = 0.0;
+        for (int i = 1; i < n; ++i) {
+            d = __dadd_rn(mx[i], d);
+            dists[f * n + i] = d;
+        }
+    }
+}
+
+inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int as_euclid_fwd(const float* out, const float* tgt, int64_t frames, int32_t A, int32_t N, float* dist,
+                             void* stream) {
+    AS_REQUIRE(out && tgt && dist && frames > 0 && A > 0 && N > 0, AS_ERR_BAD_ARG, "as_euclid_fwd: bad argument");
+    const long points = (long)frames * A * N;
+    hipLaunchKernelGGL(euclid_fwd_kernel, dim3(ew_grid(points)), dim3(256), 0, (hipStream_t)stream, out, tgt, points, N, dist);
+    AS_LAUNCH_CHECK("as_euclid_fwd");
+    return 0;
+}
+
+extern "C" int as_euclid_bwd(const float* out, const float* tgt, const float* ddist, int64_t frames, int32_t A, int32_t N,
+                             float* dout, void* stream) {
+    AS_REQUIRE(out && tgt && ddist && dout && frames > 0 && A > 0 && N > 0, AS_ERR_BAD_ARG, "as_euclid_bwd: bad argument");
+    const long points = (long)frames * A * N;
+    hipLaunchKernelGGL(euclid_bwd_kernel, dim3(ew_grid(points)), dim3(256), 0, (hipStream_t)stream, out, tgt, ddist, points, N, dout);
+    AS_LAUNCH_CHECK("as_euclid_bwd");
+    return 0;
+}
+
+extern "C" int32_t as_euclid_masked_partials(void) { return LOSS_BLOCKS; }
+
+extern "C" int as_euclid_masked_fwd_bwd(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
+                                        int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
+                                        float* partial, void* stream) {
+    AS_REQUIRE(out && tgt && lengths && loss && partial, AS_ERR_BAD_ARG, "as_euclid_masked_fwd_bwd: null pointer");
+    AS_REQUIRE(B > 0 && T > 0 && A > 0 && N > 0 && tgt_T >= T, AS_ERR_BAD_ARG,
+               "as_euclid_masked_fwd_bwd: B=%d T=%d A=%d N=%d tgt_T=%ld", B, T, A, N, (long)tgt_T);
+    const long points = (long)B * T * A * N;
+    int blocks = ew_grid(points);
+    if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(euclid_masked_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, (long)tgt_T, lengths, T, A, N, points,
+                       scale, dout, partial);
+    AS_LAUNCH_CHECK("as_euclid_masked_fwd_bwd");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, scale, loss);
+    AS_LAUNCH_CHECK("as_euclid_masked_fwd_bwd(final)");
+    return 0;
+}
+
+extern "C" int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t u_xy, int32_t n_u, const float* v,
+                           int64_t v_tile, int64_t v_pt, int64_t v_xy, int32_t n_v, int64_t tiles, float* out,
+                           void* stream) {
+    AS_REQUIRE(u && v && out && tiles > 0, AS_ERR_BAD_ARG, "as_p2cp_fwd: bad argument");
+    AS_REQUIRE(n_u > 0 && n_v > 0 && n_u <= P2CP_MAXPTS && n_v <= P2CP_MAXPTS, AS_ERR_UNSUPPORTED,
+               "as_p2cp_fwd: point counts %d, %d must be in [1, %d]", n_u, n_v, P2CP_MAXPTS);
+    const size_t shm = (size_t)4 * 2 * (n_u + n_v) * sizeof(float);
+    hipLaunchKernelGGL(p2cp_kernel, dim3(as_cdiv(tiles, 4)), dim3(256), shm, (hipStream_t)stream, u, (long)u_tile, (long)u_pt,
+                       (long)u_xy, n_u, v, (long)v_tile, (long)v_pt, (long)v_xy, n_v, (long)tiles, out);
+    AS_LAUNCH_CHECK("as_p2cp_fwd");
+    return 0;
+}
+
+extern "C" int as_p2cp_utterance_mean(const float* p2cp, const int32_t* lengths, int32_t B, int32_t T, int32_t A,
+                                      float to_mm, float* result, void* stream) {
+    AS_REQUIRE(p2cp && lengths && result && B > 0 && T > 0 && A > 0, AS_ERR_BAD_ARG, "as_p2cp_utterance_mean: bad argument");
+    hipLaunchKernelGGL(p2cp_utt_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p2cp, lengths, B, T, A, to_mm, result);
+    AS_LAUNCH_CHECK("as_p2cp_utterance_mean");
+    return 0;
+}
+
+extern "C" int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int32_t N, const int32_t* spec,
+                                      int32_t n_tv, float* values, float* poc1, float* poc2, int32_t* idx, void* stream) {
+    AS_REQUIRE(contours && spec && values && poc1 && poc2 && frames > 0 && A > 0 && N > 0 && n_tv > 0, AS_ERR_BAD_ARG,
+               "as_tract_variables_fwd: bad argument");
+    hipLaunchKernelGGL(tv_kernel, dim3(as_cdiv((long)frames * n_tv, 4)), dim3(256), 0, (hipStream_t)stream, contours,
+                       (long)frames, A, N, spec, n_tv, values, poc1, poc2, idx);
+    AS_LAUNCH_CHECK("as_tract_variables_fwd");
+    return 0;
+}
+
+extern "C" int as_area_function_fwd(const double* internal_wall, const double* external_wall, int64_t frame_stride,
+                                    int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
+                                    double beta, double* dists, double* fx, void* stream) {
+    AS_REQUIRE(internal_wall && external_wall && dists && fx && frames > 0, AS_ERR_BAD_ARG, "as_area_function_fwd: bad argument");
+    AS_REQUIRE(n_pts > 0 && n_pts <= 256, AS_ERR_UNSUPPORTED, "as_area_function_fwd: n_pts=%d must be in [1, 256]", n_pts);
+    const size_t shm = (size_t)4 * 2 * n_pts * sizeof(double);
+    hipLaunchKernelGGL(area_kernel, dim3(as_cdiv(frames, 4)), dim3(256), shm, (hipStream_t)stream, internal_wall, external_wall,
+                       (long)frame_stride, (long)pt_stride, (long)xy_stride, (long)frames, n_pts, alpha, beta,
+                       beta == 2.0 ? 1 : 0, dists, fx);
+    AS_LAUNCH_CHECK("as_area_function_fwd");
+    return 0;
+}

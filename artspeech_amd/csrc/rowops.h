@@ -1,0 +1,20 @@
+// Internal (non-ABI) launch helpers shared by the composite entry points.
+#pragma once
+#include "as_common.h"
+
+int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st);
+int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
+                     int D, hipStream_t st);
+int as_colsum_splits(long rows);
+// partial: as_colsum_splits(rows) * C floats
+int as_colsum(const float* x, long rows, int C, long ldx, float* out, float* partial, hipStream_t st);
+int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
+            int K, hipStream_t st);
+int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
+              float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st);
+int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
+                    hipStream_t st);
+int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
+                   hipStream_t st);
+int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st);
+int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st);

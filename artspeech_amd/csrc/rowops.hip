@@ -1,0 +1,338 @@
+// Row-wise and reduction kernels around the GEMMs of the contour-regression heads and the GRU:
+// affine-free LayerNorm (the affine is folded into the following Linear, see fold_kernel), its
+// backward fused with the ReLU mask, deterministic column sums (bias gradients), the fold/unfold of
+// LayerNorm affine parameters, per-token segment sums (embedding / layer-0 input-projection
+// gradients), gather, sigmoid backward and the flat Adam update.  All HBM-bound: one wave per row,
+// coalesced 4-byte or 16-byte lanes, wave shuffles for the row reductions.
+#include "rowops.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // row length <= 64 * MAXC
+
+// ---- x_hat = (x - mean) * rstd over the last dim (biased variance, eps) -------------------------
+__global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restrict__ x, float* __restrict__ xhat,
+                                                            float* __restrict__ rstd, long rows, int D, float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = i < D ? xr[i] : 0.f;
+        s += v[c];
+    }
+    const float mean = as_wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        const float d = i < D ? v[c] - mean : 0.f;
+        v[c] = d;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(as_wave_sum(q) / D + eps);
+    float* o = xhat + row * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        if (i < D) o[i] = v[c] * rs;
+    }
+    if (lane == 0) rstd[row] = rs;
+}
+
+// ---- dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) * (relu_src > 0) ------------------------
+// dy and dx may alias (in-place): a lane reads all its elements before it writes any.
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ relu_src, float* dx,
+                                                            long rows, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* dyr = dy + row * D;
+    const float* xr = xhat + row * D;
+    float g[MAXC], h[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        g[c] = i < D ? dyr[i] : 0.f;
+        h[c] = i < D ? xr[i] : 0.f;
+        s1 += g[c];
+        s2 += g[c] * h[c];
+    }
+    const float m1 = as_wave_sum(s1) / D, m2 = as_wave_sum(s2) / D;
+    const float rs = rstd[row];
+    float* o = dx + row * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        if (i < D) {
+            float v = rs * (g[c] - m1 - h[c] * m2);
+            if (relu_src && !(relu_src[row * D + i] > 0.f)) v = 0.f;
+            o[i] = v;
+        }
+    }
+}
+
+// ---- deterministic column sums: stage 1 partial[rs][C], stage 2 out[C] ---------------------------
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, long rows, int C, long ldx,
+                                                     float* __restrict__ partial, int rows_per_split) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (col < C)
+        for (long r = r0 + w; r < r1; r += 4) s += x[r * ldx + col];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && col < C) partial[(long)blockIdx.y * C + col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int splits, int C,
+                                                     float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < splits; ++i) s += partial[(long)i * C + col];
+    out[col] = s;
+}
+
+// ---- fold LayerNorm affine into the next Linear: Wf[n][k] = W[n][k] * gamma[k], bf[n] = b[n] + W[n].beta
+// grid.x = heads * R rows (one wave per row), W [heads][R][K], gamma/beta [heads][K]
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ b,
+                                                   float* __restrict__ Wf, float* __restrict__ bf, long total_rows, int R,
+                                                   int K) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    const long head = row / R;
+    const float* wr = W + row * K;
+    const float* gm = gamma + head * K;
+    const float* bt = beta + head * K;
+    float* o = Wf + row * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = wr[k];
+        o[k] = w * gm[k];
+        s += w * bt[k];
+    }
+    s = as_wave_sum(s);
+    if (lane == 0) bf[row] = b[row] + s;
+}
+
+// ---- unfold: dW[n][k] = dWf[n][k] * gamma[k] + dbf[n] * beta[k] ; dgamma[k] = sum_n dWf[n][k] W[n][k] ;
+//      dbeta[k] = sum_n dbf[n] W[n][k]      (chain rule through W' = W.diag(gamma), b' = b + W.beta)
+// grid (ceil(K/64), heads); block 256 = 4 row-lanes x 64 columns
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
+                                                     const float* __restrict__ W, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     float* __restrict__ dW, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int R, int K) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const long head = blockIdx.y;
+    float sg = 0.f, sb = 0.f;
+    if (k < K) {
+        const float gm = gamma[head * K + k], bt = beta[head * K + k];
+        for (int n = w; n < R; n += 4) {
+            const long idx = (head * R + n) * K + k;
+            const float dwf = dWf[idx], wv = W[idx], dbn = dbf[head * R + n];
+            dW[idx] = dwf * gm + dbn * bt;
+            sg += dwf * wv;
+            sb += dbn * wv;
+        }
+    }
+    r1[w][lane] = sg;
+    r2[w][lane] = sb;
+    __syncthreads();
+    if (w == 0 && k < K) {
+        dgamma[head * K + k] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+        dbeta[head * K + k] = (r2[0][lane] + r2[1][lane]) + (r2[2][lane] + r2[3][lane]);
+    }
+}
+
+// ---- out[v][:] = sum over rows m with token(m) == v of x[m][:]   (x [rows][C]) ---------------------
+// grid (V, ceil(C/256)); the block scans the token array in chunks of 256, compacts the matches IN ORDER
+// into LDS and then streams the matching rows with independent loads (bitwise reproducible).
+__global__ __launch_bounds__(256) void token_segsum_kernel(const float* __restrict__ x, const int64_t* __restrict__ tokens,
+                                                           long tok_stride, int T, long rows, int C,
+                                                           float* __restrict__ out) {
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    const int v = blockIdx.x;
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long base = 0; base < rows; base += 256) {
+        const long m = base + threadIdx.x;
+        bool match = false;
+        if (m < rows) {
+            const long b = m / T, t = m % T;
+            match = tokens[b * tok_stride + t] == v;
+        }
+        // ordered (deterministic) compaction of the matching row indices: ballot + prefix popcount
+        const unsigned long long bal = __ballot(match);
+        if (lane == 0) wcount[w] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < w; ++i) off += wcount[i];
+        const int n = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (match) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
+        __syncthreads();
+        if (col < C) {
+            int i = 0;
+            for (; i + 3 < n; i += 4) {  // four independent loads in flight; fixed summation order
+                s0 += x[(base + list[i]) * C + col];
+                s1 += x[(base + list[i + 1]) * C + col];
+                s2 += x[(base + list[i + 2]) * C + col];
+                s3 += x[(base + list[i + 3]) * C + col];
+            }
+            for (; i < n; ++i) s0 += x[(base + list[i]) * C + col];
+        }
+        __syncthreads();
+    }
+    if (col < C) out[(long)v * C + col] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- out[m][:] = table[token(m)][:] --------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ tokens,
+                                                          long tok_stride, int T, long rows, int C,
+                                                          float* __restrict__ out) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const long b = m / T, t = m % T;
+    const long v = tokens[b * tok_stride + t];
+    for (int c = threadIdx.x & 63; c < C; c += 64) out[m * C + c] = table[v * C + c];
+}
+
+// ---- dpre = dout * out * (1 - out) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                          float* __restrict__ dpre, long n) {
+    const long stride = (long)gridDim.x * 256;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 o = reinterpret_cast<const float4*>(out)[i];
+        const float4 d = reinterpret_cast<const float4*>(dout)[i];
+        float4 r;
+        r.x = d.x * o.x * (1.f - o.x); r.y = d.y * o.y * (1.f - o.y);
+        r.z = d.z * o.z * (1.f - o.z); r.w = d.w * o.w * (1.f - o.w);
+        reinterpret_cast<float4*>(dpre)[i] = r;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        dpre[i] = dout[i] * out[i] * (1.f - out[i]);
+}
+
+// ---- y = relu-masked copy: dst = (src_mask > 0) ? g : 0 ---------------------------------------------
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ g, const float* __restrict__ act,
+                                                        float* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = act[i] > 0.f ? g[i] : 0.f;
+}
+
+// ---- torch.optim.Adam (weight decay added to the gradient), flat ----------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float pi = p[i];
+        float gi = g[i] * gscale;
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = m[i] + (1.f - b1) * (gi - m[i]);      // lerp form, as torch's _single_tensor_adam
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st) {
+    AS_REQUIRE(D > 0 && D <= 64 * MAXC, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXC);
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, x, xhat, rstd, rows, D, 1e-5f);
+    AS_LAUNCH_CHECK("normalize_fwd");
+    return 0;
+}
+int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
+                     int D, hipStream_t st) {
+    AS_REQUIRE(D > 0 && D <= 64 * MAXC, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXC);
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
+    AS_LAUNCH_CHECK("normalize_bwd");
+    return 0;
+}
+int as_colsum_splits(long rows) {
+    long s = (rows + 63) / 64;
+    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+}
+int as_colsum(const float* x, long rows, int C, long ldx, float* out, float* partial, hipStream_t st) {
+    const int splits = as_colsum_splits(rows);
+    const int rps = (int)((rows + splits - 1) / splits);
+    hipLaunchKernelGGL(colsum_stage1, dim3(as_cdiv(C, 64), splits), dim3(256), 0, st, x, rows, C, ldx, partial, rps);
+    AS_LAUNCH_CHECK("colsum_stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3(as_cdiv(C, 256)), dim3(256), 0, st, partial, splits, C, out);
+    AS_LAUNCH_CHECK("colsum_stage2");
+    return 0;
+}
+int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
+            int K, hipStream_t st) {
+    const long total = (long)heads * R;
+    hipLaunchKernelGGL(fold_kernel, dim3(as_cdiv(total, 4)), dim3(256), 0, st, W, gamma, beta, b, Wf, bf, total, R, K);
+    AS_LAUNCH_CHECK("fold");
+    return 0;
+}
+int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
+              float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st) {
+    hipLaunchKernelGGL(unfold_kernel, dim3(as_cdiv(K, 64), heads), dim3(256), 0, st, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, K);
+    AS_LAUNCH_CHECK("unfold");
+    return 0;
+}
+int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(token_segsum_kernel, dim3(V, as_cdiv(C, 256)), dim3(256), 0, st, x, tokens, tok_stride, T, rows, C, out);
+    AS_LAUNCH_CHECK("token_segsum");
+    return 0;
+}
+int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, table, tokens, tok_stride, T, rows, C, out);
+    AS_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st) {
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, st, out, dout, dpre, n);
+    AS_LAUNCH_CHECK("sigmoid_bwd");
+    return 0;
+}
+int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, act, dst, n);
+    AS_LAUNCH_CHECK("relu_mask");
+    return 0;
+}
+
+extern "C" int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                            void* stream) {
+    AS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, AS_ERR_BAD_ARG, "as_adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    AS_LAUNCH_CHECK("as_adam_step");
+    return 0;
+}

@@ -1,0 +1,207 @@
+/*
+ * artspeech_hip.h -- C ABI of libartspeech_hip.so, the MI355X (gfx950) engine for the
+ * phoneme_to_articulation hot path of vribeiro1/artspeech.
+ *
+ * The reference has no FFI layer: the path sits behind PyTorch module APIs whose device work is
+ * implicit (cuDNN GRU / cuBLAS / ATen).  Each entry point below replaces the device work of one of
+ * those call sites (cited as file:line relative to the reference root).  Conventions for EVERY call:
+ *   - plain pointers and sizes only; pointers are DEVICE pointers unless the name says host;
+ *   - the caller owns every buffer (outputs, saved activations, workspaces): nothing is allocated,
+ *     freed or synchronised inside; all work is enqueued on `stream` (a hipStream_t passed as void*)
+ *     and is re-entrant per stream;
+ *   - return value: 0 on success, otherwise a hipError_t (>0) or an AS_ERR_* code (<0);
+ *     as_last_error() returns a static message for the last failing call of this thread;
+ *   - all floating-point tensors are float32, row-major, contiguous unless a stride is given;
+ *     the area function is float64 like the reference.
+ */
+#ifndef ARTSPEECH_HIP_H
+#define ARTSPEECH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AS_ERR_BAD_ARG (-1)      /* null pointer / non-positive size / unsupported combination */
+#define AS_ERR_UNSUPPORTED (-2)  /* e.g. hidden size not in {32, 64, 128} */
+#define AS_ERR_WORKSPACE (-3)    /* caller-provided workspace too small */
+
+#define AS_HEAD_HIDDEN 256 /* ArticulatorPredictor's fixed width (encoder_decoder/models.py:12-17) */
+
+const char* as_version(void);    /* "artspeech_hip <semver>" */
+const char* as_arch(void);       /* "gfx950" */
+const char* as_last_error(void); /* message of the last failing call on this thread ("" if none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Model geometry and the flat parameter layout.
+ * All parameters of ArtSpeech / SimpleArtSpeech live in ONE flat float buffer (one gradient buffer,
+ * one RCCL all-reduce, one optimizer launch).  as_artspeech_layout() is the single source of truth
+ * for where each state_dict tensor of the reference (encoder_decoder/models.py:99-124; key names in
+ * SURVEY 8b) sits in that buffer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct as_dims {
+    int32_t vocab;   /* V  : nn.Embedding rows                          (models.py:110) */
+    int32_t n_art;   /* A  : number of ArticulatorPredictor heads       (models.py:118-120) */
+    int32_t embed;   /* E  : embed_dim                                  (models.py:104) */
+    int32_t hidden;  /* H  : hidden_size (GRU width, head input width)  (models.py:105) */
+    int32_t n_samp;  /* N  : n_samples per contour                      (models.py:106) */
+    int32_t simple;  /* 0 = ArtSpeech (BiGRU, models.py:99), 1 = SimpleArtSpeech (models.py:53) */
+} as_dims;
+
+/* Offsets (in floats) of every parameter group inside the flat buffer. */
+typedef struct as_layout {
+    int64_t embedding;  /* [V][E] */
+    /* GRU, layer l in {0,1}; forward and reverse direction are ADJACENT (reverse follows forward) so
+       that both directions form one stacked matrix: w_ih[l] is [2][3H][I_l], I_0 = E, I_1 = 2H. */
+    int64_t w_ih[2], b_ih[2]; /* [2][3H][I_l], [2][3H] */
+    int64_t w_hh[2], b_hh[2]; /* [2][3H][H],   [2][3H] */
+    int64_t lin_w, lin_b;     /* linear.0: [H][2H] (ArtSpeech) or [H][E] (SimpleArtSpeech), [H] */
+    /* heads, stacked over the A predictors (predictors.{a}.*): */
+    int64_t ln1_g, ln1_b;     /* linear.0.{weight,bias}  [A][H] */
+    int64_t w1, b1;           /* linear.1                [A][256][H], [A][256] */
+    int64_t ln2_g, ln2_b;     /* linear.3                [A][256] */
+    int64_t w2, b2;           /* linear.4                [A][256][256], [A][256] */
+    int64_t ln3_g, ln3_b;     /* linear.6                [A][256] */
+    int64_t w3, b3;           /* x_coords then y_coords  [A][2][N][256], [A][2][N] */
+    int64_t total;            /* number of floats in the flat buffer (multiple of 64) */
+} as_layout;
+
+int as_artspeech_layout(const as_dims* dims, as_layout* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Workspace: one caller-allocated float buffer holds every intermediate and saved activation of a
+ * training step for a (B, T) batch.  as_artspeech_workspace_floats() returns its size in floats.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T);
+
+/* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96), dropout 0.
+ *   tokens  : int64 [B][tok_stride] phoneme indices (only the first T columns are read)
+ *   lengths : int32 [B] on the DEVICE, sorted descending, 1 <= len <= T, T == max(lengths)
+ *             (ignored when dims->simple)
+ *   out     : float [B][T][A][2][N]  sigmoid contours
+ *   train   : non-zero => keep what as_artspeech_bwd needs in `ws`
+ */
+int as_artspeech_fwd(const as_dims* dims, const float* params, const int64_t* tokens, int64_t tok_stride,
+                     const int32_t* lengths, int32_t B, int32_t T, float* out, float* ws, int32_t train,
+                     void* stream);
+
+/* Backward of the above: d(out) -> gradient of EVERY parameter, written (not accumulated) into the
+ * flat `grads` buffer (same layout as params).  Must follow as_artspeech_fwd(train=1) on the same ws. */
+int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* tokens, int64_t tok_stride,
+                     const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout,
+                     float* grads, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building blocks (each is also used by the composite entry points above)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bidirectional GRU layer recurrence on a packed batch (nn.GRU at encoder_decoder/models.py:111,137;
+ * gate order r,z,n; h0 = 0; reverse direction walks t = len_b-1..0; padded outputs are zeros).
+ *   gi      : input projections W_ih x + b_ih.  If tokens != NULL it is a TABLE [V][2][3H] indexed by
+ *             tokens[b*tok_stride + t] (embedding folded in); else it is [B*T][2][3H].
+ *   w_hh    : [2][3H][H], b_hh : [2][3H]
+ *   y       : [B][T][2H]  (forward direction in [:H], reverse in [H:])
+ *   gates   : NULL (inference) or [B][T][2][4][H] receiving r, z, n, (W_hn h + b_hn) for the backward */
+int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh,
+                     const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y,
+                     float* gates, void* stream);
+
+/* BPTT of the recurrence.  dy [B][T][2H] -> dgi, dgh [B*T][2][3H] (gradients w.r.t. the input- and
+ * hidden-projection pre-activations, zeros at padded frames); weight gradients are time-batched GEMMs
+ * over these (done by as_artspeech_bwd). */
+int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const float* w_hh,
+                     const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* dgi, float* dgh,
+                     void* stream);
+
+/* Strided-batched fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32):
+ *   C[g][i][j] (+)= act( sum_k Aop[g][i][k] * Bop[g][j][k] + bias[g][j] )
+ * Aop[i][k] = A[i*a_i + k*a_k] and Bop[j][k] = B[j*b_j + k*b_k]; one stride of each pair must be 1.
+ * act: 0 none, 1 ReLU, 2 sigmoid.  accumulate != 0 adds to C.  b_kshift/b_kT: if b_kT > 0 the B operand's
+ * reduction index k is read at k + b_kshift and is zero unless 0 <= (k % b_kT) + b_kshift < b_kT
+ * (the h_{t-1} operand of dW_hh). */
+typedef struct as_gemm {
+    const float* A; const float* B; float* C; const float* bias;
+    int32_t M, N, K;
+    int64_t a_i, a_k, b_j, b_k, ldc;
+    int32_t batch; int64_t a_batch, b_batch, c_batch, bias_batch;
+    int32_t act, accumulate;
+    int32_t b_kshift, b_kT;
+} as_gemm;
+int as_gemm_f32(const as_gemm* g, void* stream);
+
+/* ArticulatorPredictor x A + stack + sigmoid (encoder_decoder/models.py:7-33, 141-145) on rows of
+ * `x` [rows][in]: out [rows][A][2][N].  Parameters are read from the flat buffer through `lay`.
+ * ws: as_head_workspace_floats(). */
+int64_t as_head_workspace_floats(const as_dims* dims, int64_t rows);
+int as_head_fwd(const as_dims* dims, const as_layout* lay, const float* params, const float* x, int64_t rows,
+                float* out, float* ws, int32_t train, void* stream);
+/* dout [rows][A][2][N] -> dx [rows][in] and the head parameter gradients inside `grads` (flat). */
+int as_head_bwd(const as_dims* dims, const as_layout* lay, const float* params, const float* out,
+                const float* dout, int64_t rows, float* dx, float* grads, float* ws, void* stream);
+
+/* EuclideanDistance (phoneme_to_articulation/metrics.py:5-24), reduction "none":
+ * out, tgt [frames][A][2][N] -> dist [frames][A][N]. */
+int as_euclid_fwd(const float* out, const float* tgt, int64_t frames, int32_t A, int32_t N, float* dist,
+                  void* stream);
+/* d dist [frames][A][N] -> d out [frames][A][2][N] (NaN where dist == 0, like the reference). */
+int as_euclid_bwd(const float* out, const float* tgt, const float* ddist, int64_t frames, int32_t A, int32_t N,
+                  float* dout, void* stream);
+
+/* The masked mean of train_phoneme_to_articulation.py:86-90 fused with EuclideanDistance and its
+ * gradient: loss = scale * sum_{b, t < len_b} sum_{a,n} dist ; dout = d loss / d out (0 at padded frames).
+ * scale = 1 / (N_valid * A * N) with N_valid the GLOBAL number of valid frames (so that DP shards sum
+ * to the reference's mean).  out/tgt [B][T or tgt_T][A][2][N]; loss: one float, overwritten;
+ * partial: workspace of as_euclid_masked_partials() floats; dout may be NULL (evaluation). */
+int32_t as_euclid_masked_partials(void);
+int as_euclid_masked_fwd_bwd(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
+                             int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
+                             float* partial, void* stream);
+
+/* MeanP2CPDistance, reduction "none" (phoneme_to_articulation/metrics.py:27-46): for each of `tiles`
+ * independent (u, v) pairs: 0.5 * (mean_i min_j |u_i - v_j| + mean_j min_i |u_i - v_j|).
+ * Point p of tile t, coordinate c is at u[t*u_tile + p*u_pt + c*u_xy] (same for v): covers both the
+ * (*, N, 2) layout the module receives and the (*, 2, N) storage it is a transposed view of.
+ * Distances by direct differences (more accurate than torch.cdist's matmul expansion). */
+int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t u_xy, int32_t n_u, const float* v,
+                int64_t v_tile, int64_t v_pt, int64_t v_xy, int32_t n_v, int64_t tiles, float* out, void* stream);
+
+/* P2CPDistance.forward (encoder_decoder/metrics.py:18-26) reduction: p2cp [B][T][A], lengths ->
+ * result[0] = mean_b( mean_{t < len_b, a} p2cp * to_mm ). */
+int as_p2cp_utterance_mean(const float* p2cp, const int32_t* lengths, int32_t B, int32_t T, int32_t A, float to_mm,
+                           float* result, void* stream);
+
+/* Tract variables (tract_variables.py:23-35, 73-125): for each frame and each of n_tv variables the
+ * minimum pairwise distance between two point sets and the two closest points (first minimum over
+ * arr1 for each arr2 point, then first minimum over arr2).  A set is up to two (channel, start, end)
+ * segments of the frame's contours [A][2][N] concatenated.
+ *   spec: int32 [n_tv][3 segments][3] = {channel, start, end} for arr1, arr2 part 1, arr2 part 2
+ *         (channel < 0 => segment absent), on the DEVICE.
+ *   values [frames][n_tv], poc1/poc2 [frames][n_tv][2], idx int32 [frames][n_tv][2] (may be NULL). */
+int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int32_t N, const int32_t* spec,
+                           int32_t n_tv, float* values, float* poc1, float* poc2, int32_t* idx, void* stream);
+
+/* area_function (area_function.py:113-142), float64.  Wall point p, coordinate c of frame f is at
+ * w[f*frame_stride + p*pt_stride + c*xy_stride].  dists, fx: [frames][n_pts].  dists is the
+ * sequential running sum of mid-line segment lengths (same order as the reference's loop). */
+int as_area_function_fwd(const double* internal_wall, const double* external_wall, int64_t frame_stride,
+                         int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
+                         double beta, double* dists, double* fx, void* stream);
+
+/* torch.optim.Adam semantics (L2 weight decay added to the gradient; train_phoneme_to_articulation.py:
+ * 177-181) over flat buffers, one launch.  step is the 1-based step count after this update. */
+int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                 void* stream);
+
+/* Optional per-kernel-phase timing with HIP events recorded on the launch stream (for bench.py's
+ * roofline object).  as_profile_report writes "name count total_ms\n" lines (NUL terminated, truncated
+ * to buflen) and returns the untruncated length; it waits for the recorded events to complete. */
+void as_profile_enable(int32_t on);
+void as_profile_reset(void);
+int32_t as_profile_report(char* buf, int32_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTSPEECH_HIP_H */

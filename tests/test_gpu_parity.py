@@ -1,0 +1,482 @@
+"""GPU parity tests: the HIP path (through the C ABI / the drop-in modules) against the CPU oracle on
+the same seeded inputs and against the committed golden fixtures (outputs of the reference itself).
+
+Tolerances (north-star): contour coordinates within 1e-4 relative (fp32); arg-min indices bit-exact.
+Run with ``pytest -m gpu`` on an MI355X.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_wg
+from oracle import artspeech_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north-star tolerance on contour coordinates
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def assert_close(a, b, rtol=RTOL, atol=1e-6, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert err.max() <= 0, f"{what}: max violation {err.max():.3e}, relmax {relmax(a, b):.3e}"
+
+
+def T_(x, dev, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(dev)
+
+
+# ------------------------------------------------------------------------------------------- library
+def test_library_identity(dev):
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    assert L.as_arch() == b"gfx950"
+    assert L.as_version().startswith(b"artspeech_hip")
+
+
+def test_bad_arguments_are_reported(dev):
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    g = _lib.Gemm()
+    assert L.as_gemm_f32(C.byref(g), None) == -1
+    assert b"null" in L.as_last_error()
+    x = torch.zeros(4, device=dev)
+    rc = L.as_gru_bidir_fwd(_lib.ptr(x), None, 0, _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 1, 48, _lib.ptr(x), None, None)
+    assert rc == -2 and b"hidden size" in L.as_last_error()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def run_gemm(dev, A, B, M, N, K, a_i, a_k, b_j, b_k, bias=None, act=0, batch=1, ab=0, bb=0, cb=0, biasb=0, ldc=None,
+             accumulate=0, C0=None, kshift=0, kT=0):
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    ldc = ldc or N
+    Cbuf = torch.zeros(max(batch * cb, 0) + M * ldc, device=dev) if C0 is None else C0.clone()
+    g = _lib.Gemm()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), Cbuf.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.M, g.N, g.K = M, N, K
+    g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = a_i, a_k, b_j, b_k, ldc
+    g.batch, g.a_batch, g.b_batch, g.c_batch, g.bias_batch = batch, ab, bb, cb, biasb
+    g.act, g.accumulate, g.b_kshift, g.b_kT = act, accumulate, kshift, kT
+    _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+    torch.cuda.synchronize()
+    return Cbuf
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (200, 100, 128), (1, 1, 1), (257, 130, 70), (6400, 256, 128), (45, 768, 64),
+                                   (33, 17, 5), (300, 2816, 128)])
+def test_gemm_nt(dev, M, N, K):
+    rng = np.random.RandomState(M + N + K)
+    a, b, bias = rng.randn(M, K).astype(np.float32), rng.randn(N, K).astype(np.float32), rng.randn(N).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T + bias
+    for act, f in ((0, lambda x: x), (1, lambda x: np.maximum(x, 0)), (2, lambda x: 1 / (1 + np.exp(-x)))):
+        c = run_gemm(dev, T_(a, dev), T_(b, dev), M, N, K, K, 1, K, 1, bias=T_(bias, dev), act=act)
+        assert_close(c.cpu().numpy().reshape(M, N), f(ref), rtol=2e-5, atol=2e-5 * np.sqrt(K), what=f"nt act={act}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (100, 256, 100), (6400, 128, 2816), (7, 3, 9), (70, 200, 333)])
+def test_gemm_nn_tn(dev, M, N, K):
+    rng = np.random.RandomState(M * 3 + N + K)
+    # nn: C[M][N] = A[M][K] . B[K][N]
+    a, b = rng.randn(M, K).astype(np.float32), rng.randn(K, N).astype(np.float32)
+    c = run_gemm(dev, T_(a, dev), T_(b, dev), M, N, K, K, 1, 1, N)
+    assert_close(c.cpu().numpy().reshape(M, N), a.astype(np.float64) @ b, rtol=2e-5, atol=2e-5 * np.sqrt(K), what="nn")
+    # tn: C[M][N] = A[K][M]^T . B[K][N]
+    a2 = rng.randn(K, M).astype(np.float32)
+    c = run_gemm(dev, T_(a2, dev), T_(b, dev), M, N, K, 1, M, 1, N)
+    assert_close(c.cpu().numpy().reshape(M, N), a2.astype(np.float64).T @ b, rtol=2e-5, atol=2e-5 * np.sqrt(K), what="tn")
+    # accumulate
+    c0 = T_(rng.randn(M * N).astype(np.float32), dev)
+    c = run_gemm(dev, T_(a2, dev), T_(b, dev), M, N, K, 1, M, 1, N, accumulate=1, C0=c0)
+    assert_close(c.cpu().numpy().reshape(M, N), a2.astype(np.float64).T @ b + c0.cpu().numpy().reshape(M, N), rtol=2e-5,
+                 atol=2e-5 * np.sqrt(K), what="tn+acc")
+
+
+def test_gemm_batched_strided_and_shift(dev):
+    rng = np.random.RandomState(0)
+    R, A, Dh = 150, 3, 64
+    x = rng.randn(R, A, Dh).astype(np.float32)        # activations [rows][A][D]
+    w = rng.randn(A, 40, Dh).astype(np.float32)       # per-head weights
+    bias = rng.randn(A, 40).astype(np.float32)
+    out = run_gemm(dev, T_(x, dev), T_(w, dev), R, 40, Dh, A * Dh, 1, Dh, 1, bias=T_(bias, dev), batch=A, ab=Dh, bb=40 * Dh,
+                   cb=40, biasb=40, ldc=A * 40)
+    ref = np.einsum("rad,aod->rao", x.astype(np.float64), w) + bias
+    assert_close(out.cpu().numpy()[:R * A * 40].reshape(R, A, 40), ref, rtol=2e-5, atol=2e-4, what="batched")
+    # time-shifted reduction operand: dW[i][j] = sum_m dg[m][i] * y[m + s][j] with per-sequence masking
+    Bq, Tq, G, Hh = 4, 9, 24, 8
+    dg = rng.randn(Bq * Tq, G).astype(np.float32)
+    y = rng.randn(Bq * Tq, Hh).astype(np.float32)
+    for s in (-1, 1):
+        c = run_gemm(dev, T_(dg, dev), T_(y, dev), G, Hh, Bq * Tq, 1, G, 1, Hh, kshift=s, kT=Tq)
+        ysh = np.zeros_like(y).reshape(Bq, Tq, Hh)
+        yv = y.reshape(Bq, Tq, Hh)
+        if s == -1:
+            ysh[:, 1:] = yv[:, :-1]
+        else:
+            ysh[:, :-1] = yv[:, 1:]
+        assert_close(c.cpu().numpy().reshape(G, Hh), dg.astype(np.float64).T @ ysh.reshape(-1, Hh), rtol=2e-5, atol=1e-4,
+                     what=f"shift {s}")
+
+
+# ------------------------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize("H,I,B,T,lengths", [
+    (32, 16, 3, 7, [7, 4, 1]), (64, 24, 2, 11, [11, 11]), (128, 64, 4, 50, [50, 40, 30, 20]), (128, 256, 5, 33, [33, 32, 9, 2, 1]),
+])
+def test_gru_layer_fwd_bwd(dev, H, I, B, T, lengths):
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(H + I)
+    k = 1 / np.sqrt(H)
+    w_ih = rng.uniform(-k, k, (2, 3 * H, I)).astype(np.float32)
+    w_hh = rng.uniform(-k, k, (2, 3 * H, H)).astype(np.float32)
+    b_ih = rng.uniform(-k, k, (2, 3 * H)).astype(np.float32)
+    b_hh = rng.uniform(-k, k, (2, 3 * H)).astype(np.float32)
+    x = rng.randn(B, T, I).astype(np.float32)
+    lens = np.array(lengths)
+    gi = np.stack([x @ w_ih[d].T + b_ih[d] for d in range(2)], axis=2).astype(np.float32)  # [B][T][2][3H]
+    y = torch.full((B, T, 2 * H), float("nan"), device=dev)
+    gates = torch.zeros((B, T, 2, 4, H), device=dev)
+    ld = T_(lens, dev, torch.int32)
+    gi_d, whh_d, bhh_d = T_(gi, dev), T_(w_hh, dev), T_(b_hh, dev)  # keep the device buffers alive across the launch
+    _lib.check(L.as_gru_bidir_fwd(_lib.ptr(gi_d), None, 0, _lib.ptr(whh_d), _lib.ptr(bhh_d), _lib.ptr(ld),
+                                  B, T, H, _lib.ptr(y), _lib.ptr(gates), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ys, caches = [], []
+    x64 = x.astype(np.float64)
+    for d in range(2):
+        yo, c = O.gru_dir_fwd(x64, lens, w_ih[d].astype(np.float64), w_hh[d].astype(np.float64), b_ih[d].astype(np.float64),
+                              b_hh[d].astype(np.float64), reverse=bool(d))
+        ys.append(yo)
+        caches.append(c)
+    yref = np.concatenate(ys, -1)
+    assert_close(y.cpu().numpy(), yref, rtol=1e-4, atol=2e-6, what="gru y")
+    for b, l in enumerate(lens):  # padded outputs are exact zeros
+        assert np.all(y[b, l:].cpu().numpy() == 0)
+    # backward
+    dy = rng.randn(B, T, 2 * H).astype(np.float32)
+    dgi = torch.full((B * T, 2, 3 * H), float("nan"), device=dev)
+    dgh = torch.full((B * T, 2, 3 * H), float("nan"), device=dev)
+    dy_d = T_(dy, dev)
+    _lib.check(L.as_gru_bidir_bwd(_lib.ptr(dy_d), _lib.ptr(y), _lib.ptr(gates), _lib.ptr(whh_d), _lib.ptr(ld), B, T, H,
+                                  _lib.ptr(dgi), _lib.ptr(dgh), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    dgi_n, dgh_n = dgi.cpu().numpy().astype(np.float64), dgh.cpu().numpy().astype(np.float64)
+    assert np.isfinite(dgi_n).all() and np.isfinite(dgh_n).all()
+    for d in range(2):
+        dx, dwi, dwh, dbi, dbh = O.gru_dir_bwd(dy[..., d * H:(d + 1) * H].astype(np.float64), x64, ys[d], caches[d], lens,
+                                               w_ih[d].astype(np.float64), w_hh[d].astype(np.float64), reverse=bool(d))
+        # input gradient and bias gradients follow linearly from the pre-activation gradients
+        assert_close(dgi_n[:, d].reshape(B, T, -1) @ w_ih[d].astype(np.float64), dx, rtol=1e-4, atol=1e-5, what="gru dx")
+        assert_close(dgi_n[:, d].sum(0), dbi, rtol=1e-4, atol=1e-5, what="gru db_ih")
+        assert_close(dgh_n[:, d].sum(0), dbh, rtol=1e-4, atol=1e-5, what="gru db_hh")
+        assert_close(np.einsum("mg,mi->gi", dgi_n[:, d], x64.reshape(B * T, -1)), dwi, rtol=1e-4, atol=1e-5, what="gru dw_ih")
+
+
+# ------------------------------------------------------------------------------------------- heads
+@pytest.mark.parametrize("name", ["predictor_in128", "predictor_in32"])
+def test_single_head_vs_reference_fixture(dev, name):
+    """as_head_fwd/bwd with A=1 against ArticulatorPredictor fixtures (+ the model's sigmoid)."""
+    from artspeech_amd import _lib
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import _build_views, _numel
+    L = _lib.lib()
+    g = load_golden(name)
+    w, grads = split_wg(g)
+    x = g["x"].reshape(-1, g["x"].shape[-1])
+    rows, inf = x.shape
+    N = g["out"].shape[-1]
+    dims = _lib.Dims(1, 1, 1, inf, N, 1)
+    lay = _lib.layout(dims)
+    views = {k[len("predictors.0."):]: v for k, v in _build_views(dims, lay).items() if k.startswith("predictors.0.")}
+    flat = torch.zeros(lay.total)
+    for k, (off, shape) in views.items():
+        flat[off:off + _numel(shape)] = torch.from_numpy(w[k]).reshape(-1)
+    flat = flat.to(dev)
+    out = torch.empty((rows, 1, 2, N), device=dev)
+    ws = torch.empty(L.as_head_workspace_floats(C.byref(dims), rows), device=dev)
+    x_d = T_(x, dev)
+    _lib.check(L.as_head_fwd(C.byref(dims), C.byref(lay), _lib.ptr(flat), _lib.ptr(x_d), rows, _lib.ptr(out), _lib.ptr(ws), 1,
+                             _lib.stream_ptr()))
+    pre = g["out"].reshape(rows, 1, 2, N).astype(np.float64)
+    sig = 1 / (1 + np.exp(-pre))
+    assert_close(out.cpu().numpy(), sig, what="head out")
+    # backward: d(pre) = dout_fixture  =>  d(sigmoid out) = dout / (s (1 - s))
+    dsig = g["dout"].reshape(rows, 1, 2, N).astype(np.float64) / (sig * (1 - sig))
+    G = torch.zeros_like(flat)
+    dx = torch.empty((rows, inf), device=dev)
+    dsig_d = T_(dsig, dev)
+    _lib.check(L.as_head_bwd(C.byref(dims), C.byref(lay), _lib.ptr(flat), _lib.ptr(out), _lib.ptr(dsig_d), rows, _lib.ptr(dx),
+                             _lib.ptr(G), _lib.ptr(ws), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert relmax(dx.cpu().numpy(), g["dx"].reshape(rows, inf)) < 2e-4
+    Gc = G.cpu()
+    for k, (off, shape) in views.items():
+        got = Gc[off:off + _numel(shape)].view(shape).numpy()
+        assert relmax(got, grads[k]) < 2e-4, (k, relmax(got, grads[k]))
+
+
+# ------------------------------------------------------------------------------------------- models
+def _load_model(cls, g, dev, **kw):
+    w, grads = split_wg(g)
+    V, A, E, H, N = (int(v) for v in g["cfg"])
+    model = cls(V, A, embed_dim=E, hidden_size=H, **{kw.get("nkey", "n_samples"): N})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return model.to(dev), grads
+
+
+@pytest.mark.parametrize("name", ["artspeech_c1", "artspeech_small", "artspeech_h64"])
+def test_artspeech_matches_reference_fixture(dev, name):
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, masked_euclidean_loss
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDistance
+    from artspeech_amd.helpers import make_padding_mask
+    from artspeech_amd.settings import DATASET_CONFIG
+    g = load_golden(name)
+    model, grads = _load_model(ArtSpeech, g, dev)
+    x, lengths, tgt = T_(g["x"], dev, torch.int64), torch.from_numpy(g["lengths"]), T_(g["targets"], dev)
+    out = model(x, lengths)
+    assert_close(out.detach().cpu().numpy(), g["out"], what="contours")
+    # the reference's own loss expression (train_phoneme_to_articulation.py:86-90) on our modules
+    loss = EuclideanDistance("none")(out, tgt)
+    mask = make_padding_mask(lengths)
+    bs, max_len, na, nf = loss.shape
+    loss = loss.view(bs * max_len, na, nf)[mask.view(-1).to(dev)].mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    loss.backward()
+    gv = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
+    assert set(gv) == set(grads)
+    for k in grads:
+        assert relmax(gv[k], grads[k]) < 3e-4, (k, relmax(gv[k], grads[k]))
+    # fused loss gives the same value and the same gradients
+    model.zero_grad()
+    out2 = model(x, lengths)
+    loss2 = masked_euclidean_loss(out2, tgt, lengths)
+    assert abs(loss2.item() - float(g["loss"])) < 1e-6
+    loss2.backward()
+    for k, v in model.named_grad_views().items():
+        assert relmax(v.cpu().numpy(), gv[k]) < 1e-5, k
+    p2cp = P2CPDistance(DATASET_CONFIG["artspeech2"])(out.detach(), tgt, lengths)
+    assert not p2cp.is_cuda
+    assert abs(p2cp.item() - float(g["p2cp_mm"])) / float(g["p2cp_mm"]) < 2e-3  # reference cdist = fp32 mm expansion
+    oracle_p2cp = O.p2cp_distance_mm(g["out"], g["targets"], g["lengths"], 136 * 1.6176470518112)
+    assert abs(p2cp.item() - oracle_p2cp) / oracle_p2cp < 1e-5
+
+
+def test_artspeech_eval_mode_and_errors(dev):
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    g = load_golden("artspeech_small")
+    model, _ = _load_model(ArtSpeech, g, dev)
+    model.eval()
+    x, lengths = T_(g["x"], dev, torch.int64), torch.from_numpy(g["lengths"])
+    with torch.no_grad():
+        out = model(x, lengths)
+    assert_close(out.cpu().numpy(), g["out"], what="eval contours")
+    with pytest.raises(RuntimeError, match="sorted in decreasing order"):
+        model(x, torch.tensor([3, 5, 2, 1, 1]))
+    with pytest.raises(RuntimeError):
+        model(x.cpu(), lengths)
+    # shorter max length than the padded token matrix: output is cut at max(lengths)
+    with torch.no_grad():
+        out = model(x, torch.tensor([9, 9, 9, 4, 1]))
+    assert out.shape[1] == 9
+
+
+def test_simple_artspeech_matches_reference_fixture(dev):
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import SimpleArtSpeech
+    g = load_golden("simple_small")
+    model, grads = _load_model(SimpleArtSpeech, g, dev, nkey="num_samples")
+    out = model(T_(g["x"], dev, torch.int64), None)
+    assert_close(out.detach().cpu().numpy(), g["out"], what="contours")
+    (out * T_(g["dout"], dev)).sum().backward()
+    for k, v in model.named_grad_views().items():
+        assert relmax(v.cpu().numpy(), grads[k]) < 3e-4, (k, relmax(v.cpu().numpy(), grads[k]))
+
+
+def test_artspeech_vs_oracle_ragged_full_width(dev):
+    """A=11, N=50, H=128 (the benchmark architecture) at B=6, T=40 ragged, against the fp64 oracle."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(3)
+    model = ArtSpeech(45, 11)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, T = 6, 40
+    lengths = np.array([40, 37, 21, 8, 2, 1])
+    rng = np.random.RandomState(0)
+    x = rng.randint(1, 45, (B, T))
+    tgt = rng.rand(B, T, 11, 2, 50).astype(np.float32)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    loss = masked_euclidean_loss(out, T_(tgt, dev), lengths)
+    loss.backward()
+    o_out, cache = O.artspeech_fwd(sd, x, lengths, 11)
+    assert_close(out.detach().cpu().numpy(), o_out, what="contours")
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    og = O.artspeech_bwd(o_dout, cache, 11)
+    for k, v in model.named_grad_views().items():
+        assert relmax(v.cpu().numpy(), og[k]) < 3e-4, (k, relmax(v.cpu().numpy(), og[k]))
+
+
+# ------------------------------------------------------------------------------------------- metrics
+def test_metrics_match_reference_fixture(dev):
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDistance
+    from artspeech_amd import metrics as root
+    from artspeech_amd.settings import DATASET_CONFIG
+    g = load_golden("metrics")
+    out = T_(g["out"], dev).requires_grad_(True)
+    tgt = T_(g["tgt"], dev)
+    none = EuclideanDistance("none")(out, tgt)
+    assert_close(none.detach().cpu().numpy(), g["euc_none"], rtol=1e-6, atol=1e-7, what="euclid none")
+    mean = EuclideanDistance("mean")(out, tgt)
+    assert abs(mean.item() - float(g["euc_mean"])) < 1e-6
+    mean.backward()
+    assert_close(out.grad.cpu().numpy(), g["euc_mean_grad"], rtol=1e-5, atol=1e-9, what="euclid grad")
+    p = MeanP2CPDistance("none")(out.detach().transpose(-1, -2), tgt.transpose(-1, -2))
+    assert p.shape == g["p2cp_none"].shape
+    assert relmax(p.cpu().numpy(), O.p2cp_distance(g["out"], g["tgt"])) < 1e-6      # direct formula: tight vs fp64
+    assert relmax(p.cpu().numpy(), g["p2cp_none"]) < 2e-3                            # reference = fp32 mm expansion
+    assert abs(MeanP2CPDistance("mean")(out.detach().transpose(-1, -2), tgt.transpose(-1, -2)).item() - float(g["p2cp_mean"])) < 1e-4
+    small = MeanP2CPDistance("none")(T_(g["u10"], dev), T_(g["v12"], dev))          # N, M <= 25: reference direct
+    assert_close(small.cpu().numpy(), g["p2cp_small"], rtol=1e-6, atol=1e-7, what="p2cp small")
+    for db in ("artspeech2", "gottingen"):
+        v = P2CPDistance(DATASET_CONFIG[db])(out.detach(), tgt, torch.from_numpy(g["lengths"]))
+        assert abs(v.item() - float(g[f"p2cp_mm_{db}"])) / float(g[f"p2cp_mm_{db}"]) < 2e-3
+    assert relmax(root.p2cp_distance(out.detach(), tgt).cpu().numpy(), g["root_p2cp"]) < 2e-3
+    assert_close(root.euclidean_distance(out.detach(), tgt).cpu().numpy(), g["root_euclid"], rtol=1e-6, atol=1e-7, what="root euclid")
+    xc, yc = root.pearsons_correlation(out.detach(), tgt)
+    assert np.abs(xc.cpu().numpy() - g["x_corr"]).max() < 1e-5 and np.abs(yc.cpu().numpy() - g["y_corr"]).max() < 1e-5
+
+
+def test_tract_variables_match_reference_fixture(dev):
+    from artspeech_amd.tract_variables import calculate_vocal_tract_variables, tract_variables_batched
+    g = load_golden("tract_variables")
+    arts = [str(a) for a in g["articulators"]]
+    frames = T_(g["frames"], dev)
+    values, poc1, poc2, idx = tract_variables_batched(frames, arts)
+    # closest-point pairs: the very same points as the reference picked (bit-exact coordinates)
+    assert np.array_equal(poc1.cpu().numpy(), g["poc1"])
+    assert np.array_equal(poc2.cpu().numpy(), g["poc2"])
+    v = values.cpu().numpy()
+    assert np.abs(v[:, 1] - g["values"][:, 1]).max() < 1e-6          # TTCD: reference cdist direct path
+    assert np.abs(v - g["values"]).max() < 1e-4                      # others: reference's fp32 mm expansion
+    for f in range(0, frames.shape[0], 7):                           # vs the oracle: bit-exact values and indices
+        ov, _, _, oi = O.tract_variables(g["frames"][f], arts, dtype=np.float32)
+        assert np.array_equal(v[f], ov.astype(np.float32))
+        assert np.array_equal(idx[f].cpu().numpy(), oi)
+    # drop-in per-frame dict API (tract_variables.py:73-125)
+    f0 = {a: frames[0, i].T for i, a in enumerate(arts)}
+    tvs = calculate_vocal_tract_variables(f0)
+    assert tvs["LP"] is None and tvs["GLO"] is None
+    assert abs(tvs["TTCD"]["value"] - float(g["values"][0, 1])) < 1e-6
+    assert np.array_equal(tvs["LA"]["poc_1"].cpu().numpy(), g["poc1"][0, 0])
+
+
+def test_area_function_matches_reference_fixture(dev):
+    from artspeech_amd.area_function import area_function, area_function_batched
+    g = load_golden("area_function")
+    for i in range(4):
+        d, fx = area_function(g[f"int{i}"], g[f"ext{i}"])
+        assert np.array_equal(d, g[f"dists{i}"]) or np.abs(d - g[f"dists{i}"]).max() < 1e-15
+        assert np.abs(fx - g[f"fx{i}"]).max() < 1e-15
+    d, fx = area_function(g["int0"], g["ext0"], alpha=1.5, beta=1.3)
+    assert np.abs(d - g["dists0_ab"]).max() < 1e-15 and relmax(fx, g["fx0_ab"]) < 1e-14
+    # batched air-column layout (frames, 2 walls, 2, Nw) -- phoneme_recognition/datasets.py:152
+    rng = np.random.RandomState(0)
+    ac = rng.rand(300, 2, 2, 100)
+    dists, fxs = area_function_batched(torch.from_numpy(ac).to(dev))
+    for f in (0, 17, 299):
+        od, ofx = O.area_function(ac[f, 0].T, ac[f, 1].T)
+        assert np.array_equal(dists[f].cpu().numpy(), od) and np.array_equal(fxs[f].cpu().numpy(), ofx)
+
+
+def test_adam_matches_torch(dev):
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    p0 = torch.randn(10007)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-2)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn(10007)
+        ref.grad = gr.clone()
+        opt.step()
+        gr_d = gr.to(dev)
+        _lib.check(L.as_adam_step(_lib.ptr(p), _lib.ptr(gr_d), _lib.ptr(m), _lib.ptr(v), p.numel(), 1e-3, 0.9, 0.999, 1e-8,
+                                  1e-2, step, 1.0, _lib.stream_ptr()))
+    assert_close(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7, what="adam")
+
+
+# ------------------------------------------------------------------------------------------- full size
+def test_full_size_properties(dev):
+    """BASELINE config 2 (B=32, T=200, A=11, N=50): size-independent properties of the HIP path."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss, EuclideanDistance
+    torch.manual_seed(0)
+    model = ArtSpeech(45, 11).to(dev)
+    B, T = 32, 200
+    lengths = torch.linspace(200, 60, B).int()
+    x = torch.randint(1, 45, (B, T), device=dev)
+    tgt = torch.rand(B, T, 11, 2, 50, device=dev)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(x, lengths)
+    assert out.shape == (B, T, 11, 2, 50) and torch.isfinite(out).all()
+    assert out.min() > 0 and out.max() < 1
+    # (1) batch independence: an utterance alone gives the same contours as inside the batch
+    for b in (0, 13, 31):
+        l = int(lengths[b])
+        solo = model(x[b:b + 1, :l], lengths[b:b + 1])
+        assert torch.allclose(solo[0], out[b, :l], rtol=1e-5, atol=1e-6)
+    # (2) padding invariance: tokens beyond the length do not matter
+    x2 = x.clone()
+    x2[5, int(lengths[5]):] = 7
+    assert torch.equal(model(x2, lengths)[5, :int(lengths[5])], out[5, :int(lengths[5])])
+    # (3) fused masked loss == reference expression on the unfused distance
+    loss = masked_euclidean_loss(out, tgt, lengths)
+    dist = EuclideanDistance("none")(out, tgt)
+    mask = (torch.arange(T)[None, :] < lengths[:, None]).to(dev)
+    assert abs(loss.item() - dist[mask].mean().item()) < 1e-6
+    # (4) gradient: zero contribution from padded frames, finite everywhere, and a directional
+    #     finite-difference check of the whole step
+    loss.backward()
+    gflat = model.flat.grad.clone()
+    assert torch.isfinite(gflat).all() and gflat.abs().sum() > 0
+    torch.manual_seed(1)
+    direction = torch.randn_like(gflat)
+    direction /= direction.norm()
+    eps = 1e-2
+    with torch.no_grad():
+        base = model.flat.data.clone()
+        model.flat.data = base + eps * direction
+        lp = masked_euclidean_loss(model(x, lengths), tgt, lengths).item()
+        model.flat.data = base - eps * direction
+        lm = masked_euclidean_loss(model(x, lengths), tgt, lengths).item()
+        model.flat.data = base
+    fd = (lp - lm) / (2 * eps)
+    an = float((gflat * direction).sum())
+    assert abs(fd - an) < 5e-3 * max(abs(an), 1e-3) + 2e-5, (fd, an)
+    # (5) determinism: two identical steps give bit-identical gradients
+    model.zero_grad()
+    masked_euclidean_loss(model(x, lengths), tgt, lengths).backward()
+    assert torch.equal(model.flat.grad, gflat)
