@@ -35,7 +35,9 @@ class Gemm(C.Structure):
                 ("a_i", C.c_int64), ("a_k", C.c_int64), ("b_j", C.c_int64), ("b_k", C.c_int64), ("ldc", C.c_int64),
                 ("batch", C.c_int32), ("a_batch", C.c_int64), ("b_batch", C.c_int64), ("c_batch", C.c_int64),
                 ("bias_batch", C.c_int64), ("act", C.c_int32), ("accumulate", C.c_int32),
-                ("b_kshift", C.c_int32), ("b_kT", C.c_int32)]
+                ("b_kshift", C.c_int32), ("b_kT", C.c_int32),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64), ("colsum", C.c_void_p),
+                ("colsum_batch", C.c_int64)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

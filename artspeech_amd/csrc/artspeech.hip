@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int D = AS_HEAD_HIDDEN;
+constexpr int64_t SLAB_FLOATS = 8LL << 20;  // 32 MB: ~1024 partial 64x64 tiles + margin
 
 struct Carve {
     int64_t off = 0;
@@ -30,7 +31,7 @@ struct Carve {
 
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
-    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, colsum, total;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, total;
 };
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
@@ -58,10 +59,7 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.dw1f = c.take(A * D * H);
     w.dw2f = c.take(A * D * D);
     w.dw3f = c.take(A * O * D);
-    int64_t maxc = A * D;
-    if (6 * H > maxc) maxc = 6 * H;
-    if (A * O > maxc) maxc = A * O;
-    w.colsum = c.take((int64_t)128 * maxc);  // as_colsum_splits() <= 128 for any row count (also used with V rows)
+    w.slab = c.take(SLAB_FLOATS);  // split-K partial tiles of the weight-gradient GEMMs
     w.total = c.off;
     return w;
 }
@@ -128,12 +126,15 @@ int gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long 
     return as_gemm_f32(&g, st);
 }
 // C[M][N] = A[K][M]^T . B[K][N]   (weight gradient: reduction over the rows of both)
+// colsum (optional): column sums of A, i.e. the bias gradient that goes with this weight gradient, [batch][M]
 int gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
-            int batch = 1, long ab = 0, long bb = 0, long cb = 0, int kshift = 0, int kT = 0) {
+            float* slab, float* colsum = nullptr, long csb = 0, int batch = 1, long ab = 0, long bb = 0, long cb = 0,
+            int kshift = 0, int kT = 0) {
     as_gemm g{};
     g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
     g.a_i = 1; g.a_k = lda; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
     g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.b_kshift = kshift; g.b_kT = kT;
+    g.splitk_ws = slab; g.splitk_ws_floats = SLAB_FLOATS; g.colsum = colsum; g.colsum_batch = csb;
     return as_gemm_f32(&g, st);
 }
 
@@ -166,21 +167,18 @@ int head_bwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
-    float* part = ws + w.colsum;
+    float* slab = ws + w.slab;
     AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
-    // layer 3
-    AS_STEP("headb.colsum", st, as_colsum(ws + w.dpre3, rows, (int)AO, AO, G + L.b3, part, st));
-    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, A, O, D, (long)O * D));
+    // layer 3 (each weight-gradient GEMM also emits the bias gradient = column sums of its A operand)
+    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
     AS_STEP("headb.dx3", st, gemm_nn(ws + w.dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
     AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
     // layer 2
-    AS_STEP("headb.colsum", st, as_colsum(ws + w.dz2, rows, (int)AD, AD, G + L.b2, part, st));
-    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, A, D, D, (long)D * D));
+    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D));
     AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
     AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
     // layer 1 (all heads in one GEMM each way)
-    AS_STEP("headb.colsum", st, as_colsum(ws + w.dz1, rows, (int)AD, AD, G + L.b1, part, st));
-    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st));
+    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0));
     AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st));
     AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));
     // unfold the LayerNorm affines
@@ -297,41 +295,35 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     const ModelWs w = model_ws(*d, B, T);
     const HeadWs hw = head_ws(*d, (int64_t)B * T);
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
-    float* part = ws + w.head + hw.colsum;
+    float* slab = ws + w.head + hw.slab;
     float* dzlin = ws + w.head + hw.dxhat;  // reused: d(trunk pre-activation) [R][H]
     // heads (+ the trunk ReLU mask fused into the last normalize-backward)
     AS_TRY(head_bwd_impl(*d, L, P, out, dout, R, dzlin, ws + w.lin, G, ws + w.head, st));
     if (d->simple) {
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
         AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st));
-        AS_TRY(as_colsum(ws + w.dtab0, V, H, H, G + L.lin_b, part, st));
-        AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st));
+        AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st, slab, G + L.lin_b, 0));
         AS_TRY(gemm_nn(ws + w.dtab0, H, P + L.lin_w, E, G + L.embedding, E, V, E, H, st));
         return 0;
     }
     // trunk Linear(2H -> H)
-    AS_STEP("trunkb.colsum", st, as_colsum(dzlin, R, H, H, G + L.lin_b, part, st));
-    AS_STEP("trunkb.dw", st, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, st));
+    AS_STEP("trunkb.dw", st, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, st, slab, G + L.lin_b, 0));
     AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
     // GRU layer 1
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
-    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgi1, R, 6 * H, 6 * H, G + L.b_ih[1], part, st));
-    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgh1, R, 6 * H, 6 * H, G + L.b_hh[1], part, st));
-    AS_STEP("grub.dw_ih1", st, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, st));
+    AS_STEP("grub.dw_ih1", st, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, st, slab, G + L.b_ih[1], 0));
     for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
         AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, st, 1, 0, 0, 0, dir ? 1 : -1, T));
+                       3 * H, H, R, st, slab, G + L.b_hh[1] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
     // GRU layer 0
     AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
-    AS_STEP("grub.colsum", st, as_colsum(ws + w.dgh0, R, 6 * H, 6 * H, G + L.b_hh[0], part, st));
     for (int dir = 0; dir < 2; ++dir)
         AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, st, 1, 0, 0, 0, dir ? 1 : -1, T));
+                       3 * H, H, R, st, slab, G + L.b_hh[0] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
     // embedding + layer-0 input projection through the token table
     AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st));
-    AS_STEP("grub.colsum", st, as_colsum(ws + w.dtab0, V, 6 * H, 6 * H, G + L.b_ih[0], part, st));
-    AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st));
+    AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
     AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st));
     return 0;
 }

@@ -22,6 +22,12 @@ struct GemmK {
     long a_batch, b_batch, c_batch, bias_batch;
     int act, accumulate, b_kshift, b_kT;
     int a_vec, b_vec;
+    // split-K: blockIdx.y owns reduction range [y*kchunk, (y+1)*kchunk); partial tiles go to a dense slab
+    // [split][batch][M][N + has_colsum]; a second kernel sums the slabs in a fixed order (deterministic).
+    int splitk, kchunk, batch;
+    float* slab;
+    // optional fused column sum of the (output-contiguous) A operand: colsum[i] = sum_k Aop[i][k]
+    float* colsum; long colsum_batch;
 };
 
 template <int BI, bool KC> struct Img { static constexpr int size = KC ? BI * (BK + 1) : BK * BI; };
@@ -134,9 +140,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    const int nk = (g.K + BK - 1) / BK;
-    tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, 0, g.M, g.K, g.a_vec, 0, 0, tid);
-    tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, 0, g.N, g.K, g.b_vec, g.b_kshift, g.b_kT, tid);
+    const int ks = blockIdx.y;
+    const int kbeg = ks * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool do_cs = !A_KC && g.colsum != nullptr && tn_idx == 0 && tid < BM;
+    float cs_acc = 0.f;
+    tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, kbeg, g.M, kend, g.a_vec, 0, 0, tid);
+    tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, kbeg, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
     tile_store<BM, A_KC>(sA[0], ra, tid);
     tile_store<BN, B_KC>(sB[0], rb, tid);
     __syncthreads();
@@ -144,11 +155,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, (kt + 1) * BK, g.M, g.K, g.a_vec, 0, 0, tid);
-            tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, (kt + 1) * BK, g.N, g.K, g.b_vec, g.b_kshift, g.b_kT, tid);
+            tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
+            tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
         }
         const float* a_s = sA[cur];
         const float* b_s = sB[cur];
+        if (do_cs) {  // image [k][BM]: consecutive threads read consecutive words (zero padded beyond M / kend)
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) cs_acc += a_s[kk * BM + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float av[TM], bv[TN];
@@ -170,6 +185,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (g.splitk > 1) {
+        const int ncs = g.colsum ? 1 : 0;
+        const long W = g.N + ncs;
+        float* slab = g.slab + ((long)ks * g.batch + bz) * (long)g.M * W;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M) slab[(long)row * W + col] = acc[i][j][r];
+                }
+        }
+        if (do_cs && m0 + tid < g.M) slab[(long)(m0 + tid) * W + g.N] = cs_acc;
+        return;
+    }
+    if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
     const float* bias = g.bias ? g.bias + (long)bz * g.bias_batch : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -193,9 +228,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     }
 }
 
+// C (+)= sum over splits of the slab; the extra slab column (if any) is the fused column sum
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK g) {
+    const int ncs = g.colsum ? 1 : 0;
+    const long W = g.N + ncs;
+    const long per = (long)g.M * W;
+    const long total = (long)g.batch * per;
+    const long stride = (long)gridDim.x * 256;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        float s = 0.f;
+        for (int k = 0; k < g.splitk; ++k) s += g.slab[(long)k * total + idx];
+        const long bz = idx / per, rem = idx - bz * per;
+        const long row = rem / W;
+        const int col = (int)(rem - row * W);
+        if (col < g.N) {
+            float* c = g.C + bz * g.c_batch + row * g.ldc + col;
+            *c = g.accumulate ? *c + s : s;
+        } else {
+            g.colsum[bz * g.colsum_batch + row] = s;
+        }
+    }
+}
+
 template <int BM, int BN>
 int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
-    dim3 grid(as_cdiv(k.M, BM) * as_cdiv(k.N, BN), 1, batch), block(256);
+    dim3 grid(as_cdiv(k.M, BM) * as_cdiv(k.N, BN), k.splitk, batch), block(256);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, k);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, k);
     else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, k);
@@ -229,8 +286,33 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.a_vec = aligned16(g->A) && a_ld % 4 == 0 && g->a_batch % 4 == 0;
     k.b_vec = aligned16(g->B) && b_ld % 4 == 0 && g->b_batch % 4 == 0;
     hipStream_t st = (hipStream_t)stream;
+    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr;
+    k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
+    AS_REQUIRE(!(g->colsum && a_kc), AS_ERR_BAD_ARG, "as_gemm_f32: colsum needs an output-contiguous A operand (a_i == 1)");
     // 128x128 tiles once they fill the chip, else 64x64 for more workgroups
     const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
     if (big >= 256 && g->N >= 96) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
-    return launch<64, 64>(k, g->batch, a_kc, b_kc, st);
+    // few output tiles and a long reduction (weight gradients): split K over workgroups
+    const long tiles = (long)as_cdiv(g->M, 64) * as_cdiv(g->N, 64) * g->batch;
+    if (g->splitk_ws && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {
+        long sk = (1024 + tiles - 1) / tiles;
+        if (sk > g->K / 128) sk = g->K / 128;
+        if (sk > 64) sk = 64;
+        const long per = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
+        if (sk * per > g->splitk_ws_floats) sk = g->splitk_ws_floats / per;
+        if (sk > 1) {
+            k.kchunk = (int)as_round_up(as_cdiv(g->K, sk), BK);
+            k.splitk = as_cdiv(g->K, k.kchunk);
+            k.slab = g->splitk_ws;
+        }
+    }
+    AS_TRY((launch<64, 64>(k, g->batch, a_kc, b_kc, st)));
+    if (k.splitk > 1) {
+        const long total = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
+        long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, k);
+        AS_LAUNCH_CHECK("as_gemm_f32(splitk reduce)");
+    }
+    return 0;
 }

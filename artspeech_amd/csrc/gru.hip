@@ -8,10 +8,13 @@
 //     reduction index of that unit's three gate rows (96 VGPRs at H=128);
 //   * h_{t-1} lives in LDS (double buffered, ONE barrier per step); a lane's quarter is interleaved in
 //     16-byte pieces (k = 16c + 4q + i) so the four lanes of a quad read four consecutive 16-B slots:
-//     every ds_read_b128 is a conflict-free broadcast;
-//   * the three gate dot products are finished with two quad shuffles (DPP), not LDS;
+//     every ds_read_b128 is a conflict-free broadcast; all reads of a step are issued before its FMAs;
+//   * the three gate dot products are finished with two DPP quad permutes (no LDS round trip);
+//   * everything that does not depend on the recurrence (input projections, saved gates, upstream
+//     gradients) is loaded ONE STEP AHEAD, and the loop body is branch-free (redundant quad lanes store
+//     the same word) so that hipcc can count its loads and never waits for the step's own stores;
 //   * the input projections (time-parallel, W_ih x + b_ih) come precomputed; for layer 0 they are a
-//     [V] row table (embedding folded into W_ih), gathered by token id, and are prefetched one step ahead.
+//     [V] row table (embedding folded into W_ih) gathered by token id through an LDS copy of the ids.
 // The backward kernel mirrors this with W_hh^T in registers (lane owns a quarter of the 3H gate rows of
 // one hidden unit's column) and emits the pre-activation gradients; weight gradients are time-batched
 // GEMMs over them (artspeech.hip).
@@ -19,24 +22,28 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 4 lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
     return v;
 }
 
-template <int H, bool TRAIN>
+template <int H, bool TRAIN, bool TOK>
 __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
                                                         long tok_stride, const float* __restrict__ w_hh,
                                                         const float* __restrict__ b_hh, const int* __restrict__ lengths,
                                                         int T, float* __restrict__ y, float* __restrict__ gates) {
     constexpr int NC = H / 16;  // 16-float chunks of the reduction index; a lane owns 4 floats of each
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    extern __shared__ int tok_s[];  // TOK: token id of every frame of this utterance
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
     const int len = lengths[b];
 
-    float w[3][NC * 4];
+    f32x2 w[3][NC * 2];  // packed pairs: v_pk_fma_f32 does two FMAs per lane per issue slot
     {
         const float* wd = w_hh + (long)dir * 3 * H * H;
 #pragma unroll
@@ -44,7 +51,8 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const float4 v = *reinterpret_cast<const float4*>(wd + (long)(g * H + j) * H + 16 * c + 4 * q);
-                w[g][4 * c] = v.x; w[g][4 * c + 1] = v.y; w[g][4 * c + 2] = v.z; w[g][4 * c + 3] = v.w;
+                w[g][2 * c] = f32x2{v.x, v.y};
+                w[g][2 * c + 1] = f32x2{v.z, v.w};
             }
     }
     const float bh_r = b_hh[dir * 3 * H + j], bh_z = b_hh[dir * 3 * H + H + j], bh_n = b_hh[dir * 3 * H + 2 * H + j];
@@ -52,56 +60,72 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     // pad_packed_sequence: outputs of padded frames are exact zeros
     for (int t = len + (tid / H); t < T; t += 4) y[((long)b * T + t) * 2 * H + dir * H + (tid % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
+    if (TOK)
+        for (int t = tid; t < len; t += 4 * H) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
     __syncthreads();
+    if (len <= 0) return;
 
-    auto gi_row = [&](int t) -> const float* {
-        const long row = tokens ? (long)tokens[(long)b * tok_stride + t] : (long)b * T + t;
-        return gi + (row * 2 + dir) * 3 * H;
-    };
+    // Per-step addresses advance by constants: keep running (wave-uniform) element offsets instead of
+    // re-deriving them from t (the address arithmetic otherwise rivals the FMAs in issue slots).
+    const int t0 = dir ? len - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float* yb = y + dir * H + j;                               // + frame * 2H
+    float* gb = gates + (long)(dir * 4 + q) * H + j;           // + frame * 8H   (TRAIN)
+    const float* gib = gi + (long)dir * 3 * H + j;             // + row * 6H
+    long fr = (long)b * T + t0;                                // frame index of the current step
+    // select masks for the gate plane this lane stores (branch-free)
+    const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
+
     float h = 0.f;
-    float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (len > 0) {
-        const float* p = gi_row(dir ? len - 1 : 0);
-        gr = p[j]; gz = p[H + j]; gn = p[2 * H + j];
+    float gr, gz, gn;
+    {
+        const long row = TOK ? (long)tok_s[t0] : fr;
+        const float* p = gib + row * 6 * H;
+        gr = p[0]; gz = p[H]; gn = p[2 * H];
     }
+    int t = t0;
     for (int s = 0; s < len; ++s) {
-        const int t = dir ? len - 1 - s : s;
         const int cur = s & 1;
-        // prefetch next step's input projection (independent of the recurrence)
-        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-        if (s + 1 < len) {
-            const float* p = gi_row(dir ? t - 1 : t + 1);
-            ngr = p[j]; ngz = p[H + j]; ngn = p[2 * H + j];
-        }
+        // next step's input projection (independent of the recurrence): in flight during this step.
+        // On the last step the look-ahead re-reads the current row (stays inside the sequence).
+        const int adv = s + 1 < len ? dt : 0;
+        const long rown = TOK ? (long)tok_s[t + adv] : fr + adv;
+        const float* pn = gib + rown * 6 * H;
+        const float ngr = pn[0], ngz = pn[H], ngn = pn[2 * H];
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
-        float ar = 0.f, az = 0.f, an = 0.f;
+        float4 hv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) hv[c] = hp[4 * c + q];
+        __builtin_amdgcn_sched_barrier(0);  // keep all reads ahead of the FMAs (hipcc otherwise pairs them 2 by 2)
+        f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float4 hv = hp[4 * c + q];
-            ar = fmaf(w[0][4 * c], hv.x, ar); ar = fmaf(w[0][4 * c + 1], hv.y, ar);
-            ar = fmaf(w[0][4 * c + 2], hv.z, ar); ar = fmaf(w[0][4 * c + 3], hv.w, ar);
-            az = fmaf(w[1][4 * c], hv.x, az); az = fmaf(w[1][4 * c + 1], hv.y, az);
-            az = fmaf(w[1][4 * c + 2], hv.z, az); az = fmaf(w[1][4 * c + 3], hv.w, az);
-            an = fmaf(w[2][4 * c], hv.x, an); an = fmaf(w[2][4 * c + 1], hv.y, an);
-            an = fmaf(w[2][4 * c + 2], hv.z, an); an = fmaf(w[2][4 * c + 3], hv.w, an);
+            const f32x2 lo = {hv[c].x, hv[c].y}, hi = {hv[c].z, hv[c].w};
+            ar = __builtin_elementwise_fma(w[0][2 * c], lo, ar);
+            az = __builtin_elementwise_fma(w[1][2 * c], lo, az);
+            an = __builtin_elementwise_fma(w[2][2 * c], lo, an);
+            ar = __builtin_elementwise_fma(w[0][2 * c + 1], hi, ar);
+            az = __builtin_elementwise_fma(w[1][2 * c + 1], hi, az);
+            an = __builtin_elementwise_fma(w[2][2 * c + 1], hi, an);
         }
-        ar = quad_sum(ar); az = quad_sum(az); an = quad_sum(an);
-        const float r = as_sigmoid(gr + (ar + bh_r));
-        const float z = as_sigmoid(gz + (az + bh_z));
-        const float hn = an + bh_n;
+        const float sr = quad_sum(ar.x + ar.y), sz = quad_sum(az.x + az.y), sn = quad_sum(an.x + an.y);
+        const float r = as_sigmoid(gr + (sr + bh_r));
+        const float z = as_sigmoid(gz + (sz + bh_z));
+        const float hn = sn + bh_n;
         const float n = as_tanh(gn + r * hn);
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
-        const long fr = (long)b * T + t;
-        if (q == 0) {
-            hbuf[cur ^ 1][j] = hnew;
-            y[fr * 2 * H + dir * H + j] = hnew;
-        }
+        // the 4 lanes of a quad hold identical values: all of them store (same word) -> no divergence
+        hbuf[cur ^ 1][j] = hnew;
+        yb[fr * 2 * H] = hnew;
         if (TRAIN) {
-            const float gv = q == 0 ? r : (q == 1 ? z : (q == 2 ? n : hn));
-            gates[((fr * 2 + dir) * 4 + q) * H + j] = gv;
+            const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
+                           (__float_as_int(hn) & m3);
+            gb[fr * 8 * H] = __int_as_float(gv);
         }
         gr = ngr; gz = ngz; gn = ngn;
+        fr += dt;
+        t += dt;
         __syncthreads();
     }
 }
@@ -117,14 +141,15 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
     const int tid = threadIdx.x, k = tid >> 2, q = tid & 3;
     const int len = lengths[b];
 
-    // W_hh^T: this lane owns rows i = 16c + 4q + ii of column k
-    float wt[NC * 4];
+    // W_hh^T: this lane owns rows i = 16c + 4q + ii of column k (packed pairs for v_pk_fma_f32)
+    f32x2 wt[NC * 2];
     {
         const float* wd = w_hh + (long)dir * 3 * H * H;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) wt[4 * c + ii] = wd[(long)(16 * c + 4 * q + ii) * H + k];
+        for (int c = 0; c < NC; ++c) {
+            wt[2 * c] = f32x2{wd[(long)(16 * c + 4 * q) * H + k], wd[(long)(16 * c + 4 * q + 1) * H + k]};
+            wt[2 * c + 1] = f32x2{wd[(long)(16 * c + 4 * q + 2) * H + k], wd[(long)(16 * c + 4 * q + 3) * H + k]};
+        }
     }
     // zero the gradients of padded frames (rows feed time-batched GEMMs)
     for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += 4 * H) {
@@ -133,39 +158,75 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
         dgi[o] = 0.f;
         dgh[o] = 0.f;
     }
+    if (len <= 0) return;
+
+    // walk opposite to the forward: forward dir t = len-1..0, reverse dir t = 0..len-1; running offsets
+    const int t0 = dir ? 0 : len - 1;
+    const int dt = dir ? 1 : -1;
+    const int sel = q < 2 ? q : 2;  // gate plane this lane stores (lanes 2 and 3 store the same words)
+    const float* gtb = gates + (long)dir * 4 * H + k;   // + frame * 8H, planes at +0, +H, +2H, +3H
+    const float* yb = y + dir * H + k;                   // + frame * 2H
+    const float* dyb = dy + dir * H + k;                 // + frame * 2H
+    float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
+    float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
+    const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q >= 2 ? -1 : 0;
+    struct In { float r, z, n, hn, hprev, dyv; };
+    // h_{prev} of frame t is the output of frame t - dt... in FORWARD time: forward dir t-1, reverse dir t+1,
+    // i.e. the frame this backward walk visits NEXT (t + dt); zero beyond the sequence ends.
+    auto load = [&](long fr, bool has_prev) {
+        In v;
+        const float* gp = gtb + fr * 8 * H;
+        v.r = gp[0]; v.z = gp[H]; v.n = gp[2 * H]; v.hn = gp[3 * H];
+        const float hp = yb[(fr + (has_prev ? dt : 0)) * 2 * H];
+        v.hprev = has_prev ? hp : 0.f;
+        v.dyv = dyb[fr * 2 * H];
+        return v;
+    };
+    long fr = (long)b * T + t0;
     float dh = 0.f;
+    In cur_in = load(fr, len > 1);
     for (int s = 0; s < len; ++s) {
-        // walk opposite to the forward: forward dir t = len-1..0, reverse dir t = 0..len-1
-        const int t = dir ? s : len - 1 - s;
         const int cur = s & 1;
-        const long fr = (long)b * T + t;
-        const float* gp = gates + (fr * 2 + dir) * 4 * H;
-        const float r = gp[k], z = gp[H + k], n = gp[2 * H + k], hn = gp[3 * H + k];
-        const int tp = dir ? t + 1 : t - 1;  // frame whose output was h_{prev} of this step
-        const float hprev = (tp >= 0 && tp < len) ? y[((long)b * T + tp) * 2 * H + dir * H + k] : 0.f;
-        const float dht = dh + dy[fr * 2 * H + dir * H + k];
+        // next step's operands: in flight during this step (last step re-reads its own frame)
+        const int adv = s + 1 < len ? dt : 0;
+        const In nxt = load(fr + adv, s + 2 < len);
+        const float r = cur_in.r, z = cur_in.z, n = cur_in.n, hn = cur_in.hn;
+        const float dht = dh + cur_in.dyv;
         const float dn = dht * (1.f - z);
-        const float dz = dht * (hprev - n);
+        const float dz = dht * (cur_in.hprev - n);
         const float dnt = dn * (1.f - n * n);
         const float g_r = dnt * hn * r * (1.f - r);
         const float g_z = dz * z * (1.f - z);
         const float g_hn = dnt * r;
-        const long o = (fr * 2 + dir) * 3 * H;
-        if (q == 0) { gbuf[cur][k] = g_r; dgi[o + k] = g_r; dgh[o + k] = g_r; }
-        else if (q == 1) { gbuf[cur][H + k] = g_z; dgi[o + H + k] = g_z; dgh[o + H + k] = g_z; }
-        else if (q == 2) { gbuf[cur][2 * H + k] = g_hn; dgh[o + 2 * H + k] = g_hn; }
-        else { dgi[o + 2 * H + k] = dnt; }
+        // planes r, z, n of d/d(W_ih x + b_ih) and d/d(W_hh h + b_hh): they differ in the n plane only
+        const int rz = (__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1);
+        const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
+        const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
+        gbuf[cur][sel * H + k] = vh;
+        dgib[fr * 6 * H] = vi;
+        dghb[fr * 6 * H] = vh;
         __syncthreads();
         const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
-        float acc = 0.f;
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float4 gv = gq[4 * c + q];
-            acc = fmaf(wt[4 * c], gv.x, acc); acc = fmaf(wt[4 * c + 1], gv.y, acc);
-            acc = fmaf(wt[4 * c + 2], gv.z, acc); acc = fmaf(wt[4 * c + 3], gv.w, acc);
+        for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their 32 FMAs on 4 chains
+            float4 gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) gv[u] = gq[4 * (c0 + u) + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) {
+                    const int c = c0 + u;
+                    a0 = __builtin_elementwise_fma(wt[2 * c], f32x2{gv[u].x, gv[u].y}, a0);
+                    a1 = __builtin_elementwise_fma(wt[2 * c + 1], f32x2{gv[u].z, gv[u].w}, a1);
+                }
         }
-        acc = quad_sum(acc);
+        const float acc = quad_sum((a0.x + a0.y) + (a1.x + a1.y));
         dh = dht * z + acc;
+        cur_in = nxt;
+        fr += dt;
         // gbuf is double buffered: the next step writes gbuf[cur^1]; all reads of it (two steps ago)
         // precede the barrier above, so one barrier per step suffices.
     }
@@ -178,15 +239,18 @@ extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t 
                                 float* gates, void* stream) {
     AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_gru_bidir_fwd: null pointer");
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_fwd: B=%d T=%d", B, T);
+    AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_gru_bidir_fwd: T=%d > 32768 with a token table", T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
-#define AS_GRU_FWD(HH)                                                                                              \
-    if (gates)                                                                                                      \
-        hipLaunchKernelGGL((gru_fwd_kernel<HH, true>), grid, dim3(4 * HH), 0, st, gi, tokens, (long)tok_stride, w_hh, \
-                           b_hh, lengths, T, y, gates);                                                             \
-    else                                                                                                            \
-        hipLaunchKernelGGL((gru_fwd_kernel<HH, false>), grid, dim3(4 * HH), 0, st, gi, tokens, (long)tok_stride, w_hh, \
-                           b_hh, lengths, T, y, gates);
+    const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
+#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                      \
+    hipLaunchKernelGGL((gru_fwd_kernel<HH, TR, TK>), grid, dim3(4 * HH), shm, st, gi, tokens, (long)tok_stride, w_hh, \
+                       b_hh, lengths, T, y, gates)
+#define AS_GRU_FWD(HH)                                      \
+    if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
+    else if (gates) AS_GRU_LAUNCH(HH, true, false);         \
+    else if (tokens) AS_GRU_LAUNCH(HH, false, true);        \
+    else AS_GRU_LAUNCH(HH, false, false);
     switch (H) {
         case 32: AS_GRU_FWD(32) break;
         case 64: AS_GRU_FWD(64) break;
@@ -196,6 +260,7 @@ extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t 
             return AS_ERR_UNSUPPORTED;
     }
 #undef AS_GRU_FWD
+#undef AS_GRU_LAUNCH
     AS_LAUNCH_CHECK("as_gru_bidir_fwd");
     return 0;
 }

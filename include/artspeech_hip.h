@@ -127,6 +127,11 @@ typedef struct as_gemm {
     int32_t batch; int64_t a_batch, b_batch, c_batch, bias_batch;
     int32_t act, accumulate;
     int32_t b_kshift, b_kT;
+    /* optional: workspace enabling deterministic split-K for long reductions with few output tiles
+       (weight gradients); optional fused column sums of the A operand, colsum[g][i] = sum_k Aop[g][i][k]
+       (bias gradients; needs a_i == 1). */
+    float* splitk_ws; int64_t splitk_ws_floats;
+    float* colsum; int64_t colsum_batch;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 
