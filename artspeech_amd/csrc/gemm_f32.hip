@@ -33,11 +33,40 @@ struct GemmK {
 template <int BI, bool KC> struct Img { static constexpr int size = KC ? BI * (BK + 1) : BK * BI; };
 
 // global -> registers for one operand tile.  I = extent of the output index, K = extent of the reduction.
-template <int BI, bool KC>
+// FAST: 16-byte aligned operand whose contiguous extent is a multiple of 4, so every float4 is wholly
+// inside or wholly outside: the loads are branch-free (clamped address + select), issued back to back
+// and waited for once.  (A per-element "load or zero" branch makes hipcc wait vmcnt(0) per element.)
+template <int BI, bool KC, bool FAST>
 __device__ __forceinline__ void tile_load(float4 (&r)[BI / 32], const float* __restrict__ p, long s_i, long s_k,
                                           int i0, int k0, int I, int K, bool vec, int kshift, int kT, int tid) {
     constexpr int P = BI / 32;
-    if constexpr (KC) {
+    if constexpr (FAST && KC) {
+        const int kq = tid & 7, row0 = tid >> 3;
+        const int k = k0 + kq * 4;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const int i = i0 + row0 + 32 * pp;
+            const bool ok = i < I && k < K;
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? (long)i * s_i + k : 0L));
+            r[pp] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else if constexpr (FAST && !KC) {
+        constexpr int V4 = BI / 4;
+        constexpr int RP = 256 / V4;
+        const int iq = tid % V4, kr0 = tid / V4;
+        const int i = i0 + iq * 4;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const int k = k0 + kr0 + RP * pp;
+            bool ok = k < K && i < I;
+            if (kT > 0) {
+                const int t = k % kT + kshift;
+                ok = ok && t >= 0 && t < kT;
+            }
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? ((long)k + (kT > 0 ? kshift : 0)) * s_k + i : 0L));
+            r[pp] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else if constexpr (KC) {
         const int kq = tid & 7, row0 = tid >> 3;
         const int k = k0 + kq * 4;
 #pragma unroll
@@ -114,11 +143,14 @@ __device__ __forceinline__ float frag(const float* __restrict__ s, int i, int k)
     return KC ? s[i * (BK + 1) + k] : s[k * BI + i];
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) float sA[2][Img<BM, A_KC>::size];
-    __shared__ __attribute__((aligned(16))) float sB[2][Img<BN, B_KC>::size];
+    // ONE LDS image per operand: the next tile waits in registers while this one is consumed, so a
+    // second LDS buffer would only halve the resident workgroups (34 KB -> 4 per CU, 4 waves per SIMD:
+    // other workgroups' MFMAs fill this one's barrier / prologue / epilogue bubbles).
+    __shared__ __attribute__((aligned(16))) float sA[1][Img<BM, A_KC>::size];
+    __shared__ __attribute__((aligned(16))) float sB[1][Img<BN, B_KC>::size];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -146,17 +178,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     const bool do_cs = !A_KC && g.colsum != nullptr && tn_idx == 0 && tid < BM;
     float cs_acc = 0.f;
-    tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, kbeg, g.M, kend, g.a_vec, 0, 0, tid);
-    tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, kbeg, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+    tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg, g.M, kend, g.a_vec, 0, 0, tid);
+    tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
     tile_store<BM, A_KC>(sA[0], ra, tid);
     tile_store<BN, B_KC>(sB[0], rb, tid);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        constexpr int cur = 0;
         if (kt + 1 < nk) {
-            tile_load<BM, A_KC>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
-            tile_load<BN, B_KC>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+            tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
+            tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
         }
         const float* a_s = sA[cur];
         const float* b_s = sB[cur];
@@ -178,10 +210,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            tile_store<BM, A_KC>(sA[cur ^ 1], ra, tid);
-            tile_store<BN, B_KC>(sB[cur ^ 1], rb, tid);
+            __syncthreads();  // every wave is done reading the image
+            tile_store<BM, A_KC>(sA[0], ra, tid);
+            tile_store<BN, B_KC>(sB[0], rb, tid);
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -253,10 +286,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK g) {
 template <int BM, int BN>
 int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(as_cdiv(k.M, BM) * as_cdiv(k.N, BN), k.splitk, batch), block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, k);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, k);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, k);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, k);
+    // FAST needs whole float4s: aligned operands and contiguous extents that are multiples of 4
+    const bool fast = k.a_vec && k.b_vec && (a_kc ? k.K % 4 == 0 : k.M % 4 == 0) && (b_kc ? k.K % 4 == 0 : k.N % 4 == 0);
+#define AS_GEMM_LAUNCH(AK, BK_, F) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k)
+    if (fast) {
+        if (a_kc && b_kc) AS_GEMM_LAUNCH(true, true, true);
+        else if (a_kc && !b_kc) AS_GEMM_LAUNCH(true, false, true);
+        else if (!a_kc && b_kc) AS_GEMM_LAUNCH(false, true, true);
+        else AS_GEMM_LAUNCH(false, false, true);
+    } else {
+        if (a_kc && b_kc) AS_GEMM_LAUNCH(true, true, false);
+        else if (a_kc && !b_kc) AS_GEMM_LAUNCH(true, false, false);
+        else if (!a_kc && b_kc) AS_GEMM_LAUNCH(false, true, false);
+        else AS_GEMM_LAUNCH(false, false, false);
+    }
+#undef AS_GEMM_LAUNCH
     AS_LAUNCH_CHECK("as_gemm_f32");
     return 0;
 }
