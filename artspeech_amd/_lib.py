@@ -67,6 +67,7 @@ PROTOTYPES = {
     "as_tract_variables_fwd": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "as_area_function_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _D, _D, _P, _P, _P]),
     "as_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
+    "as_set_overlap": (None, [_I32]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),
     "as_profile_report": (_I32, [C.c_char_p, _I32]),

@@ -13,6 +13,8 @@
 //    N = A*256 columns.  The backward unfolds dW', db' into dW, dgamma, dbeta, db exactly.
 //  * heads are batched over A with strided-batched GEMMs on [rows][A][256] activations; the last GEMM
 //    writes sigmoid(.) straight into the (B, T, A, 2, N) output (:141-145).
+#include <stdlib.h>
+
 #include "rowops.h"
 
 namespace {
@@ -31,7 +33,7 @@ struct Carve {
 
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
-    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, total;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, total;
 };
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
@@ -59,7 +61,8 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.dw1f = c.take(A * D * H);
     w.dw2f = c.take(A * D * D);
     w.dw3f = c.take(A * O * D);
-    w.slab = c.take(SLAB_FLOATS);  // split-K partial tiles of the weight-gradient GEMMs
+    w.slab = c.take(SLAB_FLOATS);   // split-K partial tiles of the weight-gradient GEMMs (main stream)
+    w.slab2 = c.take(SLAB_FLOATS);  // same, for GEMMs issued on the side stream
     w.total = c.off;
     return w;
 }
@@ -160,27 +163,37 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     return 0;
 }
 
+// Backward of the heads in two parts so that the caller can put them on different streams:
+//  head_bwd_dx : the input-gradient chain (critical path towards the GRU backward)
+//  head_bwd_dw : weight/bias gradients + LayerNorm-affine unfold (only consumes what the chain left in ws)
 // relu_src: optional [rows][H] activation whose ReLU produced x (its mask is fused into the last step)
-int head_bwd_impl(const as_dims& d, const as_layout& L, const float* P, const float* out, const float* dout, int64_t rows,
-                  float* dx, const float* relu_src, float* G, float* ws, hipStream_t st) {
+int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const float* out, const float* dout, int64_t rows,
+                float* dx, const float* relu_src, float* ws, hipStream_t st) {
+    (void)L; (void)P;
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
-    float* slab = ws + w.slab;
     AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
-    // layer 3 (each weight-gradient GEMM also emits the bias gradient = column sums of its A operand)
-    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
     AS_STEP("headb.dx3", st, gemm_nn(ws + w.dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
     AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
-    // layer 2
-    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D));
     AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
     AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
-    // layer 1 (all heads in one GEMM each way)
-    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0));
     AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st));
     AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));
+    return 0;
+}
+
+int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* G, float* ws, float* slab,
+                hipStream_t st) {
+    const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
+    const HeadWs w = head_ws(d, rows);
+    const int R = (int)rows;
+    const long AD = (long)A * D, AO = (long)A * O;
+    // each weight-gradient GEMM also emits the bias gradient = column sums of its A operand
+    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
+    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D));
+    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0));
     // unfold the LayerNorm affines
     AS_STEP("headb.unfold", st, as_unfold(ws + w.dw3f, G + L.b3, P + L.w3, P + L.ln3_g, P + L.ln3_b, G + L.w3, G + L.ln3_g, G + L.ln3_b, A, O, D, st));
     AS_STEP("headb.unfold", st, as_unfold(ws + w.dw2f, G + L.b2, P + L.w2, P + L.ln2_g, P + L.ln2_b, G + L.w2, G + L.ln2_g, G + L.ln2_b, A, D, D, st));
@@ -188,7 +201,44 @@ int head_bwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     return 0;
 }
 
+// ---- library-owned side stream: weight-gradient GEMMs (throughput bound, fill the chip) run beside the
+// GRU backward recurrences (latency bound, 2*B workgroups) instead of after them.  Fork/join are
+// stream-ordered event waits: no host synchronisation, capturable in a HIP graph.
+struct Side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
+    bool ok = false;
+};
+int g_overlap = -1;  // -1: not decided yet (environment), 0: off, 1: on
+Side* side_for_current_device() {
+    static Side sides[16];
+    if (g_overlap < 0) g_overlap = getenv("ARTSPEECH_NO_OVERLAP") ? 0 : 1;
+    if (!g_overlap) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Side& sd = sides[dev];
+    if (!sd.ok) {
+        if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (auto& e : sd.fork)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        sd.ok = true;
+    }
+    return &sd;
+}
+int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    hipError_t e = hipEventRecord(ev, from);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+    if (e != hipSuccess) {
+        as_set_error("stream fork/join failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
 }  // namespace
+
+extern "C" void as_set_overlap(int32_t on) { g_overlap = on ? 1 : 0; }
 
 extern "C" int as_artspeech_layout(const as_dims* d, as_layout* out) {
     AS_TRY(check_dims(d, "as_artspeech_layout"));
@@ -251,7 +301,9 @@ extern "C" int as_head_bwd(const as_dims* d, const as_layout* lay, const float* 
     AS_TRY(check_dims(d, "as_head_bwd"));
     AS_REQUIRE(lay && params && out && dout && dx && grads && ws && rows > 0 && rows < (1LL << 31), AS_ERR_BAD_ARG,
                "as_head_bwd: bad argument");
-    return head_bwd_impl(*d, *lay, params, out, dout, rows, dx, nullptr, grads, ws, (hipStream_t)stream);
+    const HeadWs hw = head_ws(*d, rows);
+    AS_TRY(head_bwd_dx(*d, *lay, params, out, dout, rows, dx, nullptr, ws, (hipStream_t)stream));
+    return head_bwd_dw(*d, *lay, params, rows, grads, ws, ws + hw.slab, (hipStream_t)stream);
 }
 
 extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
@@ -296,34 +348,45 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     const HeadWs hw = head_ws(*d, (int64_t)B * T);
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
     float* slab = ws + w.head + hw.slab;
+    float* slab2 = ws + w.head + hw.slab2;
     float* dzlin = ws + w.head + hw.dxhat;  // reused: d(trunk pre-activation) [R][H]
-    // heads (+ the trunk ReLU mask fused into the last normalize-backward)
-    AS_TRY(head_bwd_impl(*d, L, P, out, dout, R, dzlin, ws + w.lin, G, ws + w.head, st));
+    float* hws = ws + w.head;
+    // heads: input-gradient chain (+ the trunk ReLU mask fused into the last normalize-backward)
+    AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st));
     if (d->simple) {
+        AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st));
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
         AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st));
         AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st, slab, G + L.lin_b, 0));
         AS_TRY(gemm_nn(ws + w.dtab0, H, P + L.lin_w, E, G + L.embedding, E, V, E, H, st));
         return 0;
     }
-    // trunk Linear(2H -> H)
-    AS_STEP("trunkb.dw", st, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, st, slab, G + L.lin_b, 0));
+    Side* sd = side_for_current_device();
+    hipStream_t s2 = sd ? sd->s : st;      // no side stream: everything in order on `st`
+    float* sl2 = sd ? slab2 : slab;
     AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
-    // GRU layer 1
+    // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
+    if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
-    AS_STEP("grub.dw_ih1", st, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, st, slab, G + L.b_ih[1], 0));
-    for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
-        AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, st, slab, G + L.b_hh[1] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
+    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2));
+    AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
-    // GRU layer 0
+    // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
+    if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
     AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
+    AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
+    for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
+        AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
+                       3 * H, H, R, s2, sl2, G + L.b_hh[1] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
+    // ---- layer-0 gradients: hidden-to-hidden on the side stream, embedding / input projection here
+    if (sd) AS_TRY(fork_to(st, s2, sd->fork[2]));
     for (int dir = 0; dir < 2; ++dir)
-        AS_STEP("grub.dw_hh", st, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, st, slab, G + L.b_hh[0] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
+        AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
+                       3 * H, H, R, s2, sl2, G + L.b_hh[0] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
     // embedding + layer-0 input projection through the token table
     AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st));
     AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
     AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st));
+    if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side stream's work
     return 0;
 }

@@ -130,20 +130,22 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, 
 
 // ---- unfold: dW[n][k] = dWf[n][k] * gamma[k] + dbf[n] * beta[k] ; dgamma[k] = sum_n dWf[n][k] W[n][k] ;
 //      dbeta[k] = sum_n dbf[n] W[n][k]      (chain rule through W' = W.diag(gamma), b' = b + W.beta)
-// grid (ceil(K/64), heads); block 256 = 4 row-lanes x 64 columns
-__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
-                                                     const float* __restrict__ W, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta,
-                                                     float* __restrict__ dW, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int R, int K) {
-    __shared__ float r1[4][64], r2[4][64];
+// grid (ceil(K/64), heads); block 1024 = 16 row-lanes x 64 columns (few, small matrices: favour
+// parallelism per block over block count)
+__global__ __launch_bounds__(1024) void unfold_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
+                                                      const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ dW, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int R, int K) {
+    __shared__ float r1[16][64], r2[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane;
     const long head = blockIdx.y;
     float sg = 0.f, sb = 0.f;
     if (k < K) {
         const float gm = gamma[head * K + k], bt = beta[head * K + k];
-        for (int n = w; n < R; n += 4) {
+#pragma unroll 4
+        for (int n = w; n < R; n += 16) {
             const long idx = (head * R + n) * K + k;
             const float dwf = dWf[idx], wv = W[idx], dbn = dbf[head * R + n];
             dW[idx] = dwf * gm + dbn * bt;
@@ -155,8 +157,11 @@ __global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ d
     r2[w][lane] = sb;
     __syncthreads();
     if (w == 0 && k < K) {
-        dgamma[head * K + k] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
-        dbeta[head * K + k] = (r2[0][lane] + r2[1][lane]) + (r2[2][lane] + r2[3][lane]);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += r1[i][lane]; b += r2[i][lane]; }
+        dgamma[head * K + k] = a;
+        dbeta[head * K + k] = b;
     }
 }
 
@@ -298,7 +303,7 @@ int as_fold(const float* W, const float* gamma, const float* beta, const float* 
 }
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
               float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st) {
-    hipLaunchKernelGGL(unfold_kernel, dim3(as_cdiv(K, 64), heads), dim3(256), 0, st, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, K);
+    hipLaunchKernelGGL(unfold_kernel, dim3(as_cdiv(K, 64), heads), dim3(1024), 0, st, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, K);
     AS_LAUNCH_CHECK("unfold");
     return 0;
 }

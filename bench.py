@@ -185,6 +185,7 @@ def main():
     if rank == 0 and not args.no_profile:
         L = _lib.lib()
         psteps = min(args.steps, 20)
+        L.as_set_overlap(0)  # per-kernel durations are measured with every kernel alone on the device
         L.as_profile_reset()
         L.as_profile_enable(1)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * psteps)]
@@ -192,6 +193,7 @@ def main():
             step.forward_backward(tokens, lengths_dev, targets, scale)
         torch.cuda.synchronize()
         L.as_profile_enable(0)
+        L.as_set_overlap(1)
         buf = C.create_string_buffer(1 << 16)
         L.as_profile_report(buf, len(buf))
         L.as_profile_reset()

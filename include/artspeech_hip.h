@@ -92,6 +92,11 @@ int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* to
                      const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout,
                      float* grads, float* ws, void* stream);
 
+/* as_artspeech_bwd runs the weight-gradient GEMMs on a library-owned side stream beside the GRU backward
+ * recurrences (fork/join by stream-ordered events; `stream` observes completion of everything on return
+ * order).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
+void as_set_overlap(int32_t on);
+
 /* ------------------------------------------------------------------------------------------------
  * Building blocks (each is also used by the composite entry points above)
  * ---------------------------------------------------------------------------------------------- */
