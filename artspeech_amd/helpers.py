@@ -20,3 +20,17 @@ def make_padding_mask(lengths):
     max_length = int(lengths.max())
     steps = torch.arange(1, max_length + 1, device=lengths.device)
     return steps.unsqueeze(0) <= lengths.unsqueeze(1)
+
+
+def sequences_from_dict(datadir, sequences_dict):
+    """{subject: [sequence, ...]} -> [(subject, sequence)]; an empty list selects every sequence
+    directory of the subject (reference helpers.py:63-76)."""
+    import os
+    sequences = []
+    for subj, seqs in sequences_dict.items():
+        use_seqs = seqs
+        if len(seqs) == 0:
+            use_seqs = [s for s in sorted(os.listdir(os.path.join(datadir, subj)))
+                        if os.path.isdir(os.path.join(datadir, subj, s))]
+        sequences.extend([(subj, seq) for seq in use_seqs])
+    return sequences

@@ -49,6 +49,7 @@ def _check_pair(outputs, targets):
 class EuclideanDistance(nn.Module):
     def __init__(self, reduction="mean"):
         super().__init__()
+        self.reduction_name = reduction
         self.reduction = getattr(torch, reduction, lambda x: x)
 
     def forward(self, outputs, targets):

@@ -1,0 +1,210 @@
+"""CPU tests of the host side: C-ABI surface, flat-parameter modules (state_dict contract, seed-for-seed
+initialisation), collate functions, loud failure without a GPU, and the data-parallel scheme rehearsed
+with gloo (world_size 2) using the CPU oracle as the per-rank compute."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, split_wg
+
+
+def test_header_symbols_are_exported_and_bound():
+    from artspeech_amd import _lib
+    header = open(os.path.join(ROOT, "include", "artspeech_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    L = _lib.lib()  # loads without a GPU; resolves every prototype
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported by the library"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert L.as_arch() == b"gfx950"
+
+
+def test_layout_is_disjoint_and_counts_parameters():
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech, SimpleArtSpeech
+    for cls, kw in ((ArtSpeech, {}), (SimpleArtSpeech, {})):
+        m = cls(45, 11, **kw)
+        spans = sorted((off, off + int(np.prod(shape))) for off, shape in m._views.values())
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        assert spans[-1][1] <= m.flat.numel()
+    assert ArtSpeech(45, 11).total_parameters == 1864972   # SURVEY 2.3 (reference instantiation)
+    assert ArtSpeech(45, 2).total_parameters == 732808
+    assert ArtSpeech(45, 10).total_parameters == 1739176
+
+
+def test_state_dict_contract_and_seed_for_seed_init():
+    """Same seed => the very same initial weights as the reference (fixture artspeech_c1 was created by
+    torch.manual_seed(0); ArtSpeech(45, 2) in the reference) under the reference's key names."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    g = load_golden("artspeech_c1")
+    w, _ = split_wg(g)
+    torch.manual_seed(0)
+    model = ArtSpeech(45, 2)
+    sd = model.state_dict()
+    assert set(sd) == set(w)
+    for k, v in w.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        assert np.array_equal(sd[k].numpy(), v), k
+    # round trip through load_state_dict
+    other = ArtSpeech(45, 2)
+    other.load_state_dict(sd, strict=True)
+    assert torch.equal(other.flat, model.flat)
+    # strict errors like nn.Module
+    bad = dict(sd)
+    bad.pop("embedding.weight")
+    bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Missing key|Unexpected key"):
+        other.load_state_dict(bad, strict=True)
+    bad = dict(sd)
+    bad["linear.0.bias"] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        other.load_state_dict(bad)
+
+
+def test_simple_model_state_dict_keys():
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import SimpleArtSpeech
+    g = load_golden("simple_small")
+    w, _ = split_wg(g)
+    V, A, E, H, N = (int(v) for v in g["cfg"])
+    m = SimpleArtSpeech(V, A, embed_dim=E, hidden_size=H, num_samples=N)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: v.shape for k, v in w.items()}
+
+
+def test_cpu_tensors_fail_loudly():
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance
+    m = ArtSpeech(9, 1, embed_dim=16, hidden_size=32, n_samples=5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 3, dtype=torch.long), torch.tensor([3, 2]))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        EuclideanDistance("none")(torch.rand(1, 2, 1, 2, 5), torch.rand(1, 2, 1, 2, 5))
+
+
+def test_product_code_never_imports_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "artspeech_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
+    assert "oracle" not in open(os.path.join(ROOT, "train_phoneme_to_articulation.py")).read()
+
+
+def test_collate_functions_match_reference_fixture():
+    from artspeech_amd.helpers import make_padding_mask
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import (
+        pad_sequence_collate_fn, pad_sequence_transformer_collate_fn)
+    g = load_golden("host_collate")
+    batch = []
+    for i in range(4):
+        l = len(g[f"in{i}_tokens"])
+        batch.append((f"s{i}", torch.from_numpy(g[f"in{i}_tokens"]), torch.from_numpy(g[f"in{i}_targets"]),
+                      [f"p{i}_{j}" for j in range(l)], torch.from_numpy(g[f"in{i}_refs"]), torch.tensor([], dtype=torch.int),
+                      list(range(100 * i, 100 * i + l)), torch.from_numpy(g[f"in{i}_voicing"])))
+    c8 = pad_sequence_collate_fn(batch)
+    assert len(c8) == 8
+    assert list(c8[0]) == [str(s) for s in g["ids"]]
+    assert torch.equal(c8[1], torch.from_numpy(g["tokens"])) and c8[1].dtype == torch.int64
+    assert torch.equal(c8[2], torch.from_numpy(g["targets"]))
+    assert torch.equal(c8[3], torch.from_numpy(g["lengths"])) and c8[3].dtype == torch.int32
+    assert c8[4][0] == [str(s) for s in g["phonemes0"]]
+    assert torch.equal(c8[5], torch.from_numpy(g["refs"]))
+    assert c8[6][0] == list(g["frames0"])
+    assert torch.equal(c8[7], torch.from_numpy(g["voicing"]))
+    c12 = pad_sequence_transformer_collate_fn(batch)
+    assert len(c12) == 12
+    for got, key in zip(c12[8:], ("src_kpm", "tgt_kpm", "src_mask", "tgt_mask")):
+        assert torch.equal(got, torch.from_numpy(g[key])), key
+    assert torch.equal(make_padding_mask(torch.tensor([9, 6, 2])), torch.from_numpy(g["mask_9_6_2"]))
+
+
+def test_synthetic_dataset_items():
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import SyntheticArtSpeechDataset
+    voc = {"<blank>": 0, "<unk>": 1, "a": 2, "b": 3}
+    ds = SyntheticArtSpeechDataset(5, voc, ["tongue", "lower-lip"], n_samples=7, min_len=2, max_len=6, seed=3)
+    assert ds.articulators == ["lower-lip", "tongue"] and len(ds) == 5
+    item = ds[2]
+    assert len(item) == 8 and item[1].dtype == torch.long and item[2].shape[1:] == (2, 2, 7)
+    assert item[1].min() >= 2 and torch.equal(ds[2][2], item[2])  # pad id 0 never drawn; deterministic
+
+
+def test_round_robin_sharding():
+    from artspeech_amd import distributed as dp
+    lengths = torch.tensor([9, 8, 7, 5, 3, 1], dtype=torch.int32)
+    tokens = torch.arange(6 * 9).view(6, 9)
+    targets = torch.rand(6, 9, 2, 2, 4)
+    seen = []
+    for r in range(4):
+        tok, tgt, ln, n_valid = dp.shard_batch(tokens, targets, lengths, r, 4)
+        assert n_valid == 33 and tok.shape[1] == int(ln.max()) and tgt.shape[:2] == tok.shape
+        assert bool((ln[1:] <= ln[:-1]).all())  # shard stays sorted descending
+        seen += dp.shard_indices(6, r, 4)
+    assert sorted(seen) == list(range(6))
+    with pytest.raises(ValueError):
+        dp.shard_batch(tokens[:2], targets[:2], lengths[:2], 3, 4)
+
+
+# ------------------------------------------------------------------------------------------- DP rehearsal (gloo)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from artspeech_amd import distributed as dp
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from oracle import artspeech_oracle as O  # the per-rank compute of this CPU rehearsal
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)             # ranks start different ...
+    model = ArtSpeech(13, 2, embed_dim=16, hidden_size=32, n_samples=6)
+    dp.broadcast_parameters(model)            # ... and are made identical by one broadcast
+    rng = np.random.RandomState(0)            # every rank builds the same global batch
+    B, T = 5, 9
+    lengths = torch.tensor([9, 7, 6, 3, 1], dtype=torch.int32)
+    tokens = torch.from_numpy(rng.randint(1, 13, (B, T)))
+    targets = torch.from_numpy(rng.rand(B, T, 2, 2, 6).astype(np.float32))
+    for b, l in enumerate(lengths):
+        tokens[b, l:] = 0
+        targets[b, l:] = 0
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+
+    def grads_of(tok, tgt, ln, n_valid):
+        out, cache = O.artspeech_fwd(sd, tok.numpy(), ln.numpy(), 2)
+        dist_ = O.euclidean_distance(out, tgt.numpy().astype(np.float64)[:, :out.shape[1]])
+        mask = O.make_padding_mask(ln.numpy())
+        scale = dp.loss_scale(n_valid, 2, 6)
+        loss = (dist_ * mask[:, :, None, None]).sum() * scale
+        _, dout = O.masked_euclid_loss(out, tgt.numpy()[:, :out.shape[1]], ln.numpy())
+        dout = dout * (mask.sum() * 2 * 6) * scale   # re-normalise the oracle's local mean to the global count
+        g = O.artspeech_bwd(dout, cache, 2)
+        flat = torch.zeros_like(model.flat.data)
+        for k, (off, shape) in model._views.items():
+            flat[off:off + int(np.prod(shape))] = torch.from_numpy(np.asarray(g[k], np.float32).reshape(-1))
+        return loss, flat
+
+    tok, tgt, ln, n_valid = dp.shard_batch(tokens, targets, lengths, rank, world)
+    loss, flat = grads_of(tok, tgt, ln, n_valid)
+    dp.all_reduce_flat(flat)
+    loss_t = dp.all_reduce_flat(torch.tensor([loss], dtype=torch.float64))
+    if rank == 0:
+        full_loss, full_flat = grads_of(tokens, targets, lengths, int(lengths.sum()))
+        torch.save({"loss": float(loss_t), "full_loss": float(full_loss),
+                    "err": float((flat - full_flat).abs().max() / full_flat.abs().max())}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_matches_full_batch_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert abs(res["loss"] - res["full_loss"]) < 1e-9      # shard losses SUM to the full-batch mean
+    assert res["err"] < 1e-5                               # summed shard gradients == full-batch gradients

@@ -131,3 +131,17 @@ def test_evenly_spaced_fx_properties():
 def test_padding_mask():
     g = load_golden("host_collate")
     assert np.array_equal(O.make_padding_mask(np.array([9, 6, 2])), g["mask_9_6_2"])
+
+
+def test_torch_port_matches_reference_fixture():
+    """The CPU-baseline port (stock PyTorch CPU kernels) reproduces the reference's outputs and loss."""
+    import torch
+    from oracle.torch_port import CpuPort
+    g = load_golden("artspeech_c1")
+    w, grads = split_wg(g)
+    port = CpuPort({k: torch.from_numpy(v) for k, v in w.items()}, int(g["cfg"][1]), int(g["cfg"][3]))
+    loss, out = port.step(torch.from_numpy(g["x"]), torch.from_numpy(g["lengths"]).long(), torch.from_numpy(g["targets"]))
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-6
+    assert abs(loss - float(g["loss"])) < 1e-6
+    assert relerr(port.p["linear.0.weight"].grad.numpy(), grads["linear.0.weight"]) < 1e-4
+    assert relerr(port.rnn.weight_hh_l0.grad.numpy(), grads["rnn.weight_hh_l0"]) < 1e-4
