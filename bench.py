@@ -59,6 +59,25 @@ def phase_bytes(rows):
     }
 
 
+# phase name -> kernel name as rocprofv3 prints it (for the PMC traffic table committed under profiles/)
+PMC_KERNEL = {"gru.bwd_l0": "gru_bwd_kernel<128>", "gru.bwd_l1": "gru_bwd_kernel<128>",
+              "gru.fwd_l0": "gru_fwd_kernel<128, true, true>", "gru.fwd_l1": "gru_fwd_kernel<128, true, false>"}
+
+
+def pmc_traffic(phase):
+    """HBM bytes per launch of `phase`'s kernel from the committed rocprofv3 --pmc passes (separate
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied: tools/collect_profiles.py), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if phase not in PMC_KERNEL or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    for name, rec in table.items():
+        if PMC_KERNEL[phase] in name:
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
 def make_inputs(dev, seed):
     g = torch.Generator().manual_seed(seed)
     tokens = torch.randint(1, V, (B, T), generator=g)
@@ -185,15 +204,13 @@ def main():
     if rank == 0 and not args.no_profile:
         L = _lib.lib()
         psteps = min(args.steps, 20)
-        L.as_set_overlap(0)  # per-kernel durations are measured with every kernel alone on the device
-        L.as_profile_reset()
+        L.as_profile_reset()  # same configuration as the timed region (side-stream overlap on)
         L.as_profile_enable(1)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * psteps)]
         for i in range(psteps):
             step.forward_backward(tokens, lengths_dev, targets, scale)
         torch.cuda.synchronize()
         L.as_profile_enable(0)
-        L.as_set_overlap(1)
         buf = C.create_string_buffer(1 << 16)
         L.as_profile_report(buf, len(buf))
         L.as_profile_reset()
@@ -215,7 +232,7 @@ def main():
             per_launch = nbytes.get(dom, 0)
             ach = per_launch / (per_launch_us * 1e-6) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(per_launch_us, 2),
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom), "us_per_launch": round(per_launch_us, 2),
                         "algorithmic_bytes_per_launch": per_launch,
                         "note": "dependent-step (latency) bound: 200 sequential recurrent steps per launch"}
         # whole-step view asked for by the north star: compulsory bytes of SURVEY 8(d) over the step time
