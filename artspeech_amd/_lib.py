@@ -29,6 +29,10 @@ class Layout(C.Structure):
                 ("total", C.c_int64)]
 
 
+class Opts(C.Structure):
+    _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64)]
+
+
 class Gemm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -50,8 +54,8 @@ PROTOTYPES = {
     "as_last_error": (C.c_char_p, []),
     "as_artspeech_layout": (_I32, [_DIMS, _LAY]),
     "as_artspeech_workspace_floats": (_I64, [_DIMS, _I32, _I32]),
-    "as_artspeech_fwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _I32, _P]),
-    "as_artspeech_bwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "as_artspeech_fwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _I32, C.POINTER(Opts), _P]),
+    "as_artspeech_bwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P, C.POINTER(Opts), _P]),
     "as_gru_bidir_fwd": (_I32, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gru_bidir_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gemm_f32": (_I32, [C.POINTER(Gemm), _P]),
@@ -67,6 +71,7 @@ PROTOTYPES = {
     "as_tract_variables_fwd": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "as_area_function_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _D, _D, _P, _P, _P]),
     "as_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
+    "as_dropout_fwd": (_I32, [_P, _P, _I64, _F, C.c_uint64, _P]),
     "as_set_overlap": (None, [_I32]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),

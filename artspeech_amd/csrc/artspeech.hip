@@ -68,7 +68,7 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
 }
 
 struct ModelWs {
-    int64_t tab0, y0, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
+    int64_t tab0, y0, y0d, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
 };
 
 ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
@@ -78,6 +78,7 @@ ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
     if (!d.simple) {
         w.tab0 = c.take(V * 6 * H);
         w.y0 = c.take(R * 2 * H);
+        w.y0d = c.take(R * 2 * H);  // layer-0 output after inter-layer dropout (training with p > 0)
         w.g0 = c.take(R * 8 * H);
         w.xp1 = c.take(R * 6 * H);
         w.y1 = c.take(R * 2 * H);
@@ -141,15 +142,23 @@ int gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long 
     return as_gemm_f32(&g, st);
 }
 
+// fold the LayerNorm affines into the head weights (depends on the parameters only: can run early / elsewhere)
+int head_fold(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* ws, hipStream_t st) {
+    const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
+    const HeadWs w = head_ws(d, rows);
+    AS_STEP("head.fold", st, as_fold(P + L.w1, P + L.ln1_g, P + L.ln1_b, P + L.b1, ws + w.w1f, ws + w.b1f, A, D, H, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w2, P + L.ln2_g, P + L.ln2_b, P + L.b2, ws + w.w2f, ws + w.b2f, A, D, D, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st));
+    return 0;
+}
+
 int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const float* x, int64_t rows, float* out, float* ws,
                   hipStream_t st) {
+    (void)P;
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     AS_STEP("head.norm0", st, as_normalize_fwd(x, ws + w.xhat, ws + w.rstd0, rows, H, st));
-    AS_STEP("head.fold", st, as_fold(P + L.w1, P + L.ln1_g, P + L.ln1_b, P + L.b1, ws + w.w1f, ws + w.b1f, A, D, H, st));
-    AS_STEP("head.fold", st, as_fold(P + L.w2, P + L.ln2_g, P + L.ln2_b, P + L.b2, ws + w.w2f, ws + w.b2f, A, D, D, st));
-    AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st));
     // GEMM 1: all heads at once (shared x_hat): r1 [rows][A*D]
     AS_STEP("head.gemm1", st, gemm_nt(ws + w.xhat, H, ws + w.w1f, H, ws + w.r1, (long)A * D, ws + w.b1f, R, A * D, H, 1, st));
     AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st));
@@ -293,6 +302,7 @@ extern "C" int as_head_fwd(const as_dims* d, const as_layout* lay, const float* 
     (void)train;  // the forward keeps its activations in ws either way
     AS_TRY(check_dims(d, "as_head_fwd"));
     AS_REQUIRE(lay && params && x && out && ws && rows > 0 && rows < (1LL << 31), AS_ERR_BAD_ARG, "as_head_fwd: bad argument");
+    AS_TRY(head_fold(*d, *lay, params, rows, ws, (hipStream_t)stream));
     return head_fwd_impl(*d, *lay, params, x, rows, out, ws, (hipStream_t)stream);
 }
 
@@ -308,8 +318,11 @@ extern "C" int as_head_bwd(const as_dims* d, const as_layout* lay, const float* 
 
 extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
                                 const int32_t* lengths, int32_t B, int32_t T, float* out, float* ws, int32_t train,
-                                void* stream) {
+                                const as_opts* opts, void* stream) {
     AS_TRY(check_dims(d, "as_artspeech_fwd"));
+    const float pdrop = (opts && train) ? opts->gru_dropout : 0.f;
+    AS_REQUIRE(pdrop >= 0.f && pdrop < 1.f, AS_ERR_BAD_ARG, "as_artspeech_fwd: dropout %g not in [0, 1)", (double)pdrop);
+    AS_REQUIRE(!(pdrop > 0.f && d->simple), AS_ERR_UNSUPPORTED, "as_artspeech_fwd: dropout is built for the GRU model only");
     AS_REQUIRE(P && tokens && out && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG, "as_artspeech_fwd: bad argument");
     AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_fwd: lengths required for the GRU model");
     AS_REQUIRE((int64_t)B * T < (1LL << 31), AS_ERR_BAD_ARG, "as_artspeech_fwd: B*T too large");
@@ -318,12 +331,29 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(as_artspeech_layout(d, &L));
     const ModelWs w = model_ws(*d, B, T);
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
+    // the weight folds depend on the parameters only: run them on the side stream beside the recurrences
+    Side* sd = d->simple ? nullptr : side_for_current_device();
+    if (sd) {
+        AS_TRY(fork_to(st, sd->s, sd->fork[0]));
+        AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->s));
+        if (hipEventRecord(sd->join, sd->s) != hipSuccess) {
+            as_set_error("as_artspeech_fwd: event record failed");
+            return AS_ERR_BAD_ARG;
+        }
+    } else {
+        AS_TRY(head_fold(*d, L, P, R, ws + w.head, st));
+    }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
         AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));
         AS_STEP("gru.fwd_l0", st, as_gru_bidir_fwd(ws + w.tab0, tokens, tok_stride, P + L.w_hh[0], P + L.b_hh[0], lengths, B, T, H, ws + w.y0,
                                 train ? ws + w.g0 : nullptr, st));
-        AS_STEP("gru.xproj1", st, gemm_nt(ws + w.y0, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
+        const float* l1_in = ws + w.y0;
+        if (pdrop > 0.f) {  // nn.GRU inter-layer dropout: layer 1 sees the dropped layer-0 output
+            AS_STEP("gru.dropout", st, as_dropout(ws + w.y0, ws + w.y0d, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
+            l1_in = ws + w.y0d;
+        }
+        AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
         AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
                                 train ? ws + w.g1 : nullptr, st));
         AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
@@ -331,13 +361,19 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
         AS_TRY(gemm_nt(P + L.embedding, E, P + L.lin_w, E, ws + w.tab0, H, P + L.lin_b, V, H, E, 1, st));
         AS_TRY(as_gather_rows(ws + w.tab0, tokens, tok_stride, T, R, H, ws + w.lin, st));
     }
+    if (sd && hipStreamWaitEvent(st, sd->join, 0) != hipSuccess) {  // folded weights ready before head GEMM 1
+        as_set_error("as_artspeech_fwd: stream wait failed");
+        return AS_ERR_BAD_ARG;
+    }
     return head_fwd_impl(*d, L, P, ws + w.lin, R, out, ws + w.head, st);
 }
 
 extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
                                 const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout, float* G,
-                                float* ws, void* stream) {
+                                float* ws, const as_opts* opts, void* stream) {
     AS_TRY(check_dims(d, "as_artspeech_bwd"));
+    const float pdrop = opts ? opts->gru_dropout : 0.f;
+    AS_REQUIRE(pdrop >= 0.f && pdrop < 1.f && !(pdrop > 0.f && d->simple), AS_ERR_BAD_ARG, "as_artspeech_bwd: bad dropout option");
     AS_REQUIRE(P && tokens && out && dout && G && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG,
                "as_artspeech_bwd: bad argument");
     AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_bwd: lengths required for the GRU model");
@@ -371,10 +407,12 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
+    if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
+        AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
     AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
-    AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
+    AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
     for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
         AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
                        3 * H, H, R, s2, sl2, G + L.b_hh[1] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));

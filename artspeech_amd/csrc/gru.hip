@@ -20,6 +20,24 @@
 // GEMMs over them (artspeech.hip).
 #include "as_common.h"
 
+#ifndef AS_ABL
+#define AS_ABL 0  // ablation switch for tools/ablate (0 = the real kernel)
+#endif
+// diagnostic build (AS_ABL == 6) only: cycle stamps around the segments of one recurrent step
+#if AS_ABL == 6
+#define AS_STAMP(i)                                                                  \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        unsigned long long t__;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        seg[i] += t__ - tprev;                                                       \
+        tprev = t__;                                                                 \
+    } while (0)
+#else
+#define AS_STAMP(i)
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -76,6 +94,10 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     // select masks for the gate plane this lane stores (branch-free)
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
 
+#if AS_ABL == 6  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tprev = c0;
+#endif
     float h = 0.f;
     float gr, gz, gn;
     {
@@ -86,20 +108,22 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     int t = t0;
     for (int s = 0; s < len; ++s) {
         const int cur = s & 1;
+        AS_STAMP(0);  // loop overhead / barrier exit
         // next step's input projection (independent of the recurrence): in flight during this step.
         // On the last step the look-ahead re-reads the current row (stays inside the sequence).
         const int adv = s + 1 < len ? dt : 0;
         const long rown = TOK ? (long)tok_s[t + adv] : fr + adv;
         const float* pn = gib + rown * 6 * H;
-        const float ngr = pn[0], ngz = pn[H], ngn = pn[2 * H];
+        const float ngr = AS_ABL == 2 ? 0.1f : pn[0], ngz = AS_ABL == 2 ? 0.1f : pn[H], ngn = AS_ABL == 2 ? 0.1f : pn[2 * H];
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
         float4 hv[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) hv[c] = hp[4 * c + q];
+        for (int c = 0; c < NC; ++c) hv[c] = (AS_ABL == 4 && c > 0) ? hv[0] : hp[4 * c + q];
         __builtin_amdgcn_sched_barrier(0);  // keep all reads ahead of the FMAs (hipcc otherwise pairs them 2 by 2)
+        AS_STAMP(1);  // prefetch issue + LDS reads landed
         f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < ((AS_ABL == 3 || AS_ABL == 4) ? 1 : NC); ++c) {
             const f32x2 lo = {hv[c].x, hv[c].y}, hi = {hv[c].z, hv[c].w};
             ar = __builtin_elementwise_fma(w[0][2 * c], lo, ar);
             az = __builtin_elementwise_fma(w[1][2 * c], lo, az);
@@ -109,16 +133,20 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
             an = __builtin_elementwise_fma(w[2][2 * c + 1], hi, an);
         }
         const float sr = quad_sum(ar.x + ar.y), sz = quad_sum(az.x + az.y), sn = quad_sum(an.x + an.y);
-        const float r = as_sigmoid(gr + (sr + bh_r));
-        const float z = as_sigmoid(gz + (sz + bh_z));
+        asm volatile("" ::"v"(sr), "v"(sz), "v"(sn));
+        AS_STAMP(2);  // FMAs + quad reductions
+        const float r = AS_ABL == 5 ? gr + (sr + bh_r) : as_sigmoid(gr + (sr + bh_r));
+        const float z = AS_ABL == 5 ? 0.5f + 0.01f * (gz + (sz + bh_z)) : as_sigmoid(gz + (sz + bh_z));
         const float hn = sn + bh_n;
-        const float n = as_tanh(gn + r * hn);
+        const float n = AS_ABL == 5 ? 0.01f * (gn + r * hn) : as_tanh(gn + r * hn);
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
+        asm volatile("" ::"v"(hnew));
+        AS_STAMP(3);  // gate math
         // the 4 lanes of a quad hold identical values: all of them store (same word) -> no divergence
         hbuf[cur ^ 1][j] = hnew;
-        yb[fr * 2 * H] = hnew;
-        if (TRAIN) {
+        if (AS_ABL != 1) yb[fr * 2 * H] = hnew;
+        if (TRAIN && AS_ABL != 1) {
             const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
                            (__float_as_int(hn) & m3);
             gb[fr * 8 * H] = __int_as_float(gv);
@@ -126,8 +154,19 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
         gr = ngr; gz = ngz; gn = ngn;
         fr += dt;
         t += dt;
+        AS_STAMP(4);  // LDS write + global stores issued
         __syncthreads();
+        AS_STAMP(5);  // barrier
     }
+#if AS_ABL == 6
+    if (tid == 0 && b == 0 && dir == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(gates);
+        dbg[0] = c1 - c0;
+        dbg[1] = r1 - r0;
+        for (int i = 0; i < 6; ++i) dbg[2 + i] = seg[i];
+    }
+#endif
 }
 
 template <int H>

@@ -18,3 +18,5 @@ int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, i
                    hipStream_t st);
 int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st);
 int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st);
+// y = x * mask(seed, i) / (1 - p); x == y allowed (in place); the same (seed, p) regenerates the same mask
+int as_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t st);

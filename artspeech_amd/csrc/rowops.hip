@@ -261,6 +261,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- inverted dropout with a counter-based generator: y[i] = x[i] * keep(seed, i) / (1 - p) -----------
+// keep() is a pure function of (seed, element index) (splitmix64 finaliser), so the backward regenerates
+// the very same mask from the seed instead of storing it.
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0, 1)
+    return u >= p ? inv_keep : 0.f;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long n, float p, float inv_keep,
+                                                      unsigned long long seed) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = x[i] * dropout_scale(seed, i, p, inv_keep);
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -324,10 +341,20 @@ int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hip
     AS_LAUNCH_CHECK("sigmoid_bwd");
     return 0;
 }
+int as_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, n, p, 1.0f / (1.0f - p), seed);
+    AS_LAUNCH_CHECK("dropout");
+    return 0;
+}
 int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st) {
     hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, act, dst, n);
     AS_LAUNCH_CHECK("relu_mask");
     return 0;
+}
+
+extern "C" int as_dropout_fwd(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    AS_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, AS_ERR_BAD_ARG, "as_dropout_fwd: bad argument");
+    return as_dropout(x, y, (long)n, p, seed, (hipStream_t)stream);
 }
 
 extern "C" int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

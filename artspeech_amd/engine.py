@@ -46,13 +46,13 @@ class TrainStep:
         P = self.model.flat.data
         B, T = self.B, self.T
         _lib.check(L.as_artspeech_fwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
-                                      B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, st), "as_artspeech_fwd")
+                                      B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, None, st), "as_artspeech_fwd")
         _lib.check(L.as_euclid_masked_fwd_bwd(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1], _lib.ptr(lengths_dev),
                                               B, T, d.n_art, d.n_samp, float(loss_scale), _lib.ptr(self.loss),
                                               _lib.ptr(self.dout), _lib.ptr(self.partial), st), "as_euclid_masked_fwd_bwd")
         _lib.check(L.as_artspeech_bwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.dout), _lib.ptr(self.grads), _lib.ptr(self.ws),
-                                      st), "as_artspeech_bwd")
+                                      None, st), "as_artspeech_bwd")
 
     def all_reduce(self):
         """One RCCL all-reduce (SUM) of the flat gradient buffer: shard losses are scaled by the GLOBAL

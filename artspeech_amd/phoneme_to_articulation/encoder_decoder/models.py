@@ -94,7 +94,7 @@ class _ArtSpeechFn(torch.autograd.Function):
     as_artspeech_fwd / as_artspeech_bwd (C ABI)."""
 
     @staticmethod
-    def forward(ctx, flat, tokens, lengths_dev, dims, B, T):
+    def forward(ctx, flat, tokens, lengths_dev, dims, B, T, opts=None):
         L = _lib.lib()
         train = bool(ctx.needs_input_grad[0])  # (grad mode is always off inside Function.forward)
         out = torch.empty((B, T, dims.n_art, 2, dims.n_samp), dtype=torch.float32, device=flat.device)
@@ -104,23 +104,24 @@ class _ArtSpeechFn(torch.autograd.Function):
         ws = torch.empty(n_ws, dtype=torch.float32, device=flat.device)
         _lib.check(L.as_artspeech_fwd(C.byref(dims), _lib.ptr(flat), _lib.ptr(tokens), tokens.stride(0),
                                       _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(ws), int(train),
-                                      _lib.stream_ptr()), "as_artspeech_fwd")
+                                      C.byref(opts) if opts is not None else None, _lib.stream_ptr()), "as_artspeech_fwd")
         if train:
             ctx.save_for_backward(flat, tokens, lengths_dev, out, ws)
-            ctx.meta = (dims, B, T)
+            ctx.meta = (dims, B, T, opts)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         flat, tokens, lengths_dev, out, ws = ctx.saved_tensors
-        dims, B, T = ctx.meta
+        dims, B, T, opts = ctx.meta
         L = _lib.lib()
         dout = dout.contiguous()
         grads = torch.zeros_like(flat)  # padding words between parameter groups stay zero
         _lib.check(L.as_artspeech_bwd(C.byref(dims), _lib.ptr(flat), _lib.ptr(tokens), tokens.stride(0),
                                       _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(dout), _lib.ptr(grads),
-                                      _lib.ptr(ws), _lib.stream_ptr()), "as_artspeech_bwd")
-        return grads, None, None, None, None, None
+                                      _lib.ptr(ws), C.byref(opts) if opts is not None else None, _lib.stream_ptr()),
+                   "as_artspeech_bwd")
+        return grads, None, None, None, None, None, None
 
 
 class _FlatModule(nn.Module):
@@ -193,8 +194,6 @@ class ArtSpeech(_FlatModule):
         Return:
             (bs, max(lengths), n_articulators, 2, n_samples)
         """
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("ArtSpeech: inter-layer GRU dropout > 0 in training mode is not built yet")
         _lib.require_gpu(x, "x")
         _lib.require_gpu(self.flat, "model parameters")
         lengths_cpu = torch.as_tensor(lengths, dtype=torch.int32, device="cpu")
@@ -214,7 +213,12 @@ class ArtSpeech(_FlatModule):
         if x.stride(1) != 1:
             x = x.contiguous()
         lengths_dev = lengths_cpu.to(x.device, non_blocking=True)
-        return _ArtSpeechFn.apply(self.flat, x, lengths_dev, self.dims, x.shape[0], T)
+        opts = None
+        if self.training and self.dropout > 0.0:
+            # nn.GRU(dropout=p): inter-layer dropout in training mode.  The seed is drawn from torch's CPU
+            # generator, so torch.manual_seed() controls it (statistical parity with the reference's mask).
+            opts = _lib.Opts(self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return _ArtSpeechFn.apply(self.flat, x, lengths_dev, self.dims, x.shape[0], T, opts)
 
 
 class SimpleArtSpeech(_FlatModule):

@@ -75,7 +75,15 @@ int as_artspeech_layout(const as_dims* dims, as_layout* out);
  * ---------------------------------------------------------------------------------------------- */
 int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T);
 
-/* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96), dropout 0.
+/* Per-call training options (NULL = none).  gru_dropout: nn.GRU's inter-layer dropout (models.py:111; applied
+ * to the layer-0 output in training mode only).  The mask is a pure function of (dropout_seed, element): pass the
+ * SAME options to the matching as_artspeech_bwd.  Statistical, not bitwise, parity with torch's generator. */
+typedef struct as_opts {
+    float gru_dropout;      /* 0 <= p < 1 */
+    uint64_t dropout_seed;
+} as_opts;
+
+/* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96).
  *   tokens  : int64 [B][tok_stride] phoneme indices (only the first T columns are read)
  *   lengths : int32 [B] on the DEVICE, sorted descending, 1 <= len <= T, T == max(lengths)
  *             (ignored when dims->simple)
@@ -84,13 +92,13 @@ int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T)
  */
 int as_artspeech_fwd(const as_dims* dims, const float* params, const int64_t* tokens, int64_t tok_stride,
                      const int32_t* lengths, int32_t B, int32_t T, float* out, float* ws, int32_t train,
-                     void* stream);
+                     const as_opts* opts, void* stream);
 
 /* Backward of the above: d(out) -> gradient of EVERY parameter, written (not accumulated) into the
  * flat `grads` buffer (same layout as params).  Must follow as_artspeech_fwd(train=1) on the same ws. */
 int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* tokens, int64_t tok_stride,
                      const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout,
-                     float* grads, float* ws, void* stream);
+                     float* grads, float* ws, const as_opts* opts, void* stream);
 
 /* as_artspeech_bwd runs the weight-gradient GEMMs on a library-owned side stream beside the GRU backward
  * recurrences (fork/join by stream-ordered events; `stream` observes completion of everything on return
@@ -197,6 +205,10 @@ int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int
 int as_area_function_fwd(const double* internal_wall, const double* external_wall, int64_t frame_stride,
                          int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
                          double beta, double* dists, double* fx, void* stream);
+
+/* Inverted dropout with the library's counter-based mask: y[i] = x[i] * keep(seed, i) / (1 - p); x == y allowed.
+ * The same (p, seed) regenerates the same mask (that is how the backward works). */
+int as_dropout_fwd(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* torch.optim.Adam semantics (L2 weight decay added to the gradient; train_phoneme_to_articulation.py:
  * 177-181) over flat buffers, one launch.  step is the 1-based step count after this update. */

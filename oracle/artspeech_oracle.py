@@ -195,8 +195,9 @@ def heads_bwd(dout, out, caches, params, n_art):
     return dlin, grads
 
 
-def artspeech_fwd(params, x, lengths, n_art, dtype=np.float64):
-    """ArtSpeech.forward (encoder_decoder/models.py:126-145), dropout 0.
+def artspeech_fwd(params, x, lengths, n_art, dtype=np.float64, interlayer_scale=None):
+    """ArtSpeech.forward (encoder_decoder/models.py:126-145).  interlayer_scale: optional (B, T, 2H) array
+    mask / (1 - p) of nn.GRU's inter-layer dropout (training mode); None = dropout 0.
     params: state_dict as numpy; x (B, T) int; lengths (B,) sorted descending.
     Returns out (B, max(len), A, 2, N) and a cache for artspeech_bwd."""
     p = _cast(params, dtype)
@@ -214,15 +215,17 @@ def artspeech_fwd(params, x, lengths, n_art, dtype=np.float64):
             cs.append(c)
         out_l = np.concatenate(ys, axis=-1)
         gru_cache.append((layer_in, ys, cs))
+        if l == 0 and interlayer_scale is not None:
+            out_l = out_l * np.asarray(interlayer_scale, dtype)[:, :T]
         layer_in = out_l
     zlin = layer_in @ p["linear.0.weight"].T + p["linear.0.bias"]  # models.py:113-116,140
     lin = np.maximum(zlin, 0.0)
     out, head_caches = heads_fwd(lin, p, n_art)
-    return out, (p, x, lengths, gru_cache, layer_in, zlin, head_caches, out)
+    return out, (p, x, lengths, gru_cache, layer_in, zlin, head_caches, out, interlayer_scale)
 
 
 def artspeech_bwd(dout, cache, n_art):
-    p, x, lengths, gru_cache, rnn_out, zlin, head_caches, out = cache
+    p, x, lengths, gru_cache, rnn_out, zlin, head_caches, out, interlayer_scale = cache
     H = p["rnn.weight_hh_l0"].shape[1]
     dlin, grads = heads_bwd(dout, out, head_caches, p, n_art)
     dz = dlin * (zlin > 0)
@@ -240,6 +243,8 @@ def artspeech_bwd(dout, cache, n_art):
             grads[f"rnn.weight_ih_l{l}{sfx}"], grads[f"rnn.weight_hh_l{l}{sfx}"] = dwi, dwh
             grads[f"rnn.bias_ih_l{l}{sfx}"], grads[f"rnn.bias_hh_l{l}{sfx}"] = dbi, dbh
         dlayer = dxs
+        if l == 1 and interlayer_scale is not None:
+            dlayer = dlayer * np.asarray(interlayer_scale, dlayer.dtype)[:, :dlayer.shape[1]]
     demb = np.zeros_like(p["embedding.weight"])
     np.add.at(demb, x.reshape(-1), F(dlayer))
     grads["embedding.weight"] = demb

@@ -1,0 +1,60 @@
+"""Micro-benchmark of the GRU recurrence kernels alone (C ABI), optionally against an alternative
+library build (ARTSPEECH_LIB=path) for ablation studies.  usage: python tools/bench_gru.py [iters]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from artspeech_amd import _lib  # noqa: E402
+
+if os.environ.get("ARTSPEECH_LIB"):
+    _lib.LIB_PATH = os.environ["ARTSPEECH_LIB"]
+L = _lib.lib()
+dev = torch.device("cuda:0")
+B, T, H = 32, 200, 128
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+gi = torch.randn(B * T, 2, 3 * H, device=dev)
+w_hh = torch.randn(2, 3 * H, H, device=dev) * 0.05
+b_hh = torch.randn(2, 3 * H, device=dev) * 0.05
+lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
+y = torch.empty(B, T, 2 * H, device=dev)
+gates = torch.empty(B, T, 2, 4, H, device=dev)
+dy = torch.randn(B, T, 2 * H, device=dev)
+dgi = torch.empty(B * T, 2, 3 * H, device=dev)
+dgh = torch.empty(B * T, 2, 3 * H, device=dev)
+st = _lib.stream_ptr()
+
+
+def fwd():
+    return L.as_gru_bidir_fwd(_lib.ptr(gi), None, 0, _lib.ptr(w_hh), _lib.ptr(b_hh), _lib.ptr(lengths), B, T, H, _lib.ptr(y),
+                              _lib.ptr(gates), st)
+
+
+def bwd():
+    return L.as_gru_bidir_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(gates), _lib.ptr(w_hh), _lib.ptr(lengths), B, T, H,
+                              _lib.ptr(dgi), _lib.ptr(dgh), st)
+
+
+for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for _ in range(3):
+        _lib.check(fn())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    print(f"{os.environ.get('ARTSPEECH_LIB', 'default')[-24:]:24s} gru {name}: {us:8.1f} us/launch  {us / T * 1e3:7.1f} ns/step", flush=True)
+
+if "abl6" in os.environ.get("ARTSPEECH_LIB", ""):
+    for _ in range(200):
+        fwd()
+    torch.cuda.synchronize()
+    dbg = gates.view(-1)[:16].view(torch.int64).cpu()
+    print("segments (cycles/step): " + ", ".join(f"{n} {int(dbg[2 + i]) / T:.0f}" for i, n in enumerate(
+        ["loop/exit", "prefetch+LDS read", "FMA+reduce", "gates", "stores+LDS write", "barrier"])), flush=True)
+    print(f"in-kernel: {int(dbg[0])} shader cycles over {int(dbg[1])} x 10 ns => clock {int(dbg[0]) / int(dbg[1]) * 100:.0f} MHz, "
+          f"{int(dbg[0]) / T:.0f} cycles/step", flush=True)
