@@ -41,7 +41,8 @@ class Gemm(C.Structure):
                 ("bias_batch", C.c_int64), ("act", C.c_int32), ("accumulate", C.c_int32),
                 ("b_kshift", C.c_int32), ("b_kT", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64), ("colsum", C.c_void_p),
-                ("colsum_batch", C.c_int64)]
+                ("colsum_batch", C.c_int64), ("a_off", C.c_void_p), ("b_off", C.c_void_p), ("c_off", C.c_void_p),
+                ("bias_off", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
@@ -72,6 +73,12 @@ PROTOTYPES = {
     "as_area_function_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _D, _D, _P, _P, _P]),
     "as_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
     "as_dropout_fwd": (_I32, [_P, _P, _I64, _F, C.c_uint64, _P]),
+    "as_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _P]),
+    "as_fold_ln": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "as_attn_softmax": (_I32, [_P, _I64, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "as_embed_posenc": (_I32, [_P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "as_add": (_I32, [_P, _P, _P, _I64, _P]),
+    "as_row_scale": (_I32, [_P, _P, _P, _I64, _I32, _P]),
     "as_set_overlap": (None, [_I32]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),

@@ -28,6 +28,8 @@ struct GemmK {
     float* slab;
     // optional fused column sum of the (output-contiguous) A operand: colsum[i] = sum_k Aop[i][k]
     float* colsum; long colsum_batch;
+    // grouped batches: per-batch element offsets (device arrays) override the linear batch strides
+    const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
 };
 
 template <int BI, bool KC> struct Img { static constexpr int size = KC ? BI * (BK + 1) : BK * BI; };
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     const int tm_idx = blockIdx.x % tiles_m, tn_idx = blockIdx.x / tiles_m;
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     const int bz = blockIdx.z;
-    const float* A = g.A + (long)bz * g.a_batch;
-    const float* B = g.B + (long)bz * g.b_batch;
-    float* C = g.C + (long)bz * g.c_batch;
+    const float* A = g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch);
+    const float* B = g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch);
+    float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
         return;
     }
     if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
-    const float* bias = g.bias ? g.bias + (long)bz * g.bias_batch : nullptr;
+    const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
@@ -332,13 +334,20 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr;
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
+    k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
+    k.bias_off = (const long*)g->bias_off;
+    const bool grouped = g->a_off || g->b_off || g->c_off || g->bias_off;
+    if (grouped) {  // alignment of table offsets is the caller's contract (multiples of 4 floats) -- see header
+        k.a_vec = aligned16(g->A) && a_ld % 4 == 0;
+        k.b_vec = aligned16(g->B) && b_ld % 4 == 0;
+    }
     AS_REQUIRE(!(g->colsum && a_kc), AS_ERR_BAD_ARG, "as_gemm_f32: colsum needs an output-contiguous A operand (a_i == 1)");
     // 128x128 tiles once they fill the chip, else 64x64 for more workgroups
     const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
     if (big >= 256 && g->N >= 96) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     // few output tiles and a long reduction (weight gradients): split K over workgroups
     const long tiles = (long)as_cdiv(g->M, 64) * as_cdiv(g->N, 64) * g->batch;
-    if (g->splitk_ws && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {
+    if (g->splitk_ws && !grouped && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {
         long sk = (1024 + tiles - 1) / tiles;
         if (sk > g->K / 128) sk = g->K / 128;
         if (sk > 64) sk = 64;

@@ -278,6 +278,119 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = x[i] * dropout_scale(seed, i, p, inv_keep);
 }
 
+// ---- LayerNorm with optional residual input and grouped affine ------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, float* __restrict__ xhat,
+                                                            float* __restrict__ rstd, long rows, int D, long group_rows,
+                                                            float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const float* rr = res ? res + row * D : nullptr;
+    // rows up to 64 * 32 = 2048 wide (the transformer's LayerNorm(10 * d) and LayerNorm(A * d))
+    constexpr int MAXW = 44;
+    float v[MAXW];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = i < D ? (rr ? xr[i] + rr[i] : xr[i]) : 0.f;
+        s += v[c];
+    }
+    const float mean = as_wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int i = lane + 64 * c;
+        const float d = i < D ? v[c] - mean : 0.f;
+        v[c] = d;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(as_wave_sum(q) / D + eps);
+    // group_rows > 0: consecutive blocks of rows share a parameter set; < 0: parameter set = row % (-group_rows)
+    const long g = group_rows > 0 ? row / group_rows : (group_rows < 0 ? row % (-group_rows) : 0);
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int i = lane + 64 * c;
+        if (i < D) {
+            const float xh = v[c] * rs;
+            if (xhat) xhat[row * D + i] = xh;
+            if (y) y[row * D + i] = gamma ? xh * gamma[g * D + i] + beta[g * D + i] : xh;
+        }
+    }
+    if (rstd && lane == 0) rstd[row] = rs;
+}
+
+// ---- masked softmax over the last dim of [Z][Tq][Tk], one wave per row ------------------------------
+__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s, long rows, int Tq, int Tk, int heads, int B,
+                                                           float scale, const float* __restrict__ attn_mask,
+                                                           const float* __restrict__ kpm) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const long z = row / Tq;
+    const int q = (int)(row - z * Tq);
+    const int b = (int)((z / heads) % B);
+    float* sr = s + row * Tk;
+    const float* am = attn_mask ? attn_mask + ((long)b * Tq + q) * Tk : nullptr;
+    const float* km = kpm ? kpm + (long)b * Tk : nullptr;
+    constexpr int MAXW = 16;  // Tk <= 1024
+    float v[MAXW];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int k = lane + 64 * c;
+        float x = -INFINITY;
+        if (k < Tk) {
+            x = sr[k] * scale;
+            if (am) x += am[k];
+            if (km) x += km[k];
+        }
+        v[c] = x;
+        m = fmaxf(m, x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int k = lane + 64 * c;
+        const float e = k < Tk ? expf(v[c] - m) : 0.f;  // all -inf row: -inf - -inf = NaN, like PyTorch
+        v[c] = e;
+        sum += e;
+    }
+    sum = as_wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int k = lane + 64 * c;
+        if (k < Tk) sr[k] = v[c] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_posenc_kernel(const int64_t* __restrict__ tokens, long tok_stride,
+                                                           const float* __restrict__ table, const float* __restrict__ pe,
+                                                           float* __restrict__ out, long rows, int T, int D) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const long b = m / T, t = m % T;
+    const float* src = table ? table + tokens[b * tok_stride + t] * D : out + m * D;
+    for (int c = threadIdx.x & 63; c < D; c += 64) out[m * D + c] = src[c] + pe[t * D + c];
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = b ? a[i] + b[i] : a[i];
+}
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ a, const float* __restrict__ rs,
+                                                        float* __restrict__ dst, long n, int row_len) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = a[i] * rs[i / row_len];
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -349,6 +462,57 @@ int as_dropout(const float* x, float* y, long n, float p, unsigned long long see
 int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st) {
     hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, act, dst, n);
     AS_LAUNCH_CHECK("relu_mask");
+    return 0;
+}
+
+extern "C" int as_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xhat,
+                                float* rstd, int64_t rows, int32_t D, int64_t group_rows, void* stream) {
+    AS_REQUIRE(x && (y || xhat) && rows > 0 && D > 0 && (!gamma == !beta), AS_ERR_BAD_ARG, "as_layernorm_fwd: bad argument");
+    AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd: row length %d > %d", D, 64 * 44);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, xhat,
+                       rstd, (long)rows, D, (long)group_rows, 1e-5f);
+    AS_LAUNCH_CHECK("as_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int as_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf,
+                          int32_t heads, int32_t R, int32_t K, void* stream) {
+    AS_REQUIRE(W && gamma && beta && b && Wf && bf && heads > 0 && R > 0 && K > 0, AS_ERR_BAD_ARG, "as_fold_ln: bad argument");
+    return as_fold(W, gamma, beta, b, Wf, bf, heads, R, K, (hipStream_t)stream);
+}
+
+extern "C" int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk, int32_t heads, int32_t B, float scale,
+                               const float* attn_mask, const float* key_padding_mask, void* stream) {
+    AS_REQUIRE(scores && Z > 0 && Tq > 0 && Tk > 0 && heads > 0 && B > 0, AS_ERR_BAD_ARG, "as_attn_softmax: bad argument");
+    AS_REQUIRE(Tk <= 1024, AS_ERR_UNSUPPORTED, "as_attn_softmax: Tk=%d > 1024", Tk);
+    const long rows = (long)Z * Tq;
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, rows, Tq, Tk, heads, B,
+                       scale, attn_mask, key_padding_mask);
+    AS_LAUNCH_CHECK("as_attn_softmax");
+    return 0;
+}
+
+extern "C" int as_embed_posenc(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pe, float* out,
+                               int64_t rows, int32_t T, int32_t D, void* stream) {
+    AS_REQUIRE(pe && out && rows > 0 && T > 0 && D > 0 && (!table || tokens), AS_ERR_BAD_ARG, "as_embed_posenc: bad argument");
+    hipLaunchKernelGGL(embed_posenc_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, tokens, (long)tok_stride, table,
+                       pe, out, (long)rows, T, D);
+    AS_LAUNCH_CHECK("as_embed_posenc");
+    return 0;
+}
+
+extern "C" int as_add(const float* a, const float* b, float* dst, int64_t n, void* stream) {
+    AS_REQUIRE(a && dst && n > 0, AS_ERR_BAD_ARG, "as_add: bad argument");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, dst, (long)n);
+    AS_LAUNCH_CHECK("as_add");
+    return 0;
+}
+
+extern "C" int as_row_scale(const float* a, const float* row_scale, float* dst, int64_t rows, int32_t row_len, void* stream) {
+    AS_REQUIRE(a && row_scale && dst && rows > 0 && row_len > 0, AS_ERR_BAD_ARG, "as_row_scale: bad argument");
+    const long n = (long)rows * row_len;
+    hipLaunchKernelGGL(row_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, row_scale, dst, n, row_len);
+    AS_LAUNCH_CHECK("as_row_scale");
     return 0;
 }
 

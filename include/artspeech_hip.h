@@ -145,6 +145,11 @@ typedef struct as_gemm {
        (bias gradients; needs a_i == 1). */
     float* splitk_ws; int64_t splitk_ws_floats;
     float* colsum; int64_t colsum_batch;
+    /* optional GROUPED batches: device arrays of `batch` element offsets that replace g*x_batch for the
+       corresponding operand (NULL = linear stride).  Offsets must be multiples of 4 floats.  Used by the
+       multi-channel transformer decoder, whose 132 attention blocks per layer read/write irregular
+       (channel, head) slices. */
+    const int64_t* a_off; const int64_t* b_off; const int64_t* c_off; const int64_t* bias_off;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 
@@ -205,6 +210,34 @@ int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int
 int as_area_function_fwd(const double* internal_wall, const double* external_wall, int64_t frame_stride,
                          int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
                          double beta, double* dists, double* fx, void* stream);
+
+/* ---- row operators used by the transformer variant (transformer/models.py) ---------------------------
+ * LayerNorm over the last dim (eps 1e-5, biased variance): y = LN(x + res) * gamma + beta.
+ * res, gamma/beta (NULL = none / affine-free), xhat and rstd (NULL = not kept) are optional.
+ * gamma/beta: group_rows > 0: `group_rows` consecutive rows per parameter set (group g uses gamma + g*D);
+ * group_rows < 0: parameter set = row % (-group_rows) (interleaved channels); 0 = one set. */
+int as_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xhat,
+                     float* rstd, int64_t rows, int32_t D, int64_t group_rows, void* stream);
+
+/* Fold a LayerNorm affine into the following Linear for `heads` independent (W [R][K], gamma/beta [K], b [R])
+ * sets: Wf = W.diag(gamma), bf = b + W.beta (then Linear(LN(x)) == x_hat . Wf^T + bf). */
+int as_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int32_t heads,
+               int32_t R, int32_t K, void* stream);
+
+/* In-place masked softmax over the last dim of scores [Z][Tq][Tk] (nn.MultiheadAttention semantics with float
+ * masks): p = softmax(s * scale + attn_mask[b][q][k] + key_padding_mask[b][k]), b = (z / heads) % B.
+ * attn_mask / key_padding_mask may be NULL.  A fully masked row gives NaN, as in PyTorch. */
+int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk, int32_t heads, int32_t B, float scale,
+                    const float* attn_mask, const float* key_padding_mask, void* stream);
+
+/* out[m][:] = table[tokens[m]][:] + pe[m % T][:]  (Embedding + PositionalEncoding, transformer/models.py:9-34,368-369);
+ * table == NULL: out[m][:] += pe[m % T][:] in place. */
+int as_embed_posenc(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pe, float* out,
+                    int64_t rows, int32_t T, int32_t D, void* stream);
+
+/* dst[i] = a[i] + b[i] (b may be NULL: copy) and dst[i] = a[i] * m[i / row_len] (row mask) */
+int as_add(const float* a, const float* b, float* dst, int64_t n, void* stream);
+int as_row_scale(const float* a, const float* row_scale, float* dst, int64_t rows, int32_t row_len, void* stream);
 
 /* Inverted dropout with the library's counter-based mask: y[i] = x[i] * keep(seed, i) / (1 - p); x == y allowed.
  * The same (p, seed) regenerates the same mask (that is how the backward works). */

@@ -249,6 +249,69 @@ def gen_host(helpers, dataset):
     save("host_collate", **arrays)
 
 
+def gen_transformer(tmod, dataset):
+    """ArtSpeechTransformer (transformer/models.py:280-474): forward as the trainer calls it
+    (train_phoneme_to_articulation_transformer.py:99-111) and generate() as the test loop calls it
+    (transformer/evaluation.py:63-67).  The reference is pinned to torch 2.0.1, whose nn.TransformerDecoder
+    simply loops over its layers; torch 2.10's version probes layers[0].self_attn (absent on the custom
+    layer), so the decoder's forward is replaced by that 2.0.1 loop here (oracle-side only)."""
+    import types as _t
+    torch.manual_seed(21)
+    V, A, d, heads, L, nf = 13, 3, 32, 4, 2, 20
+    model = tmod.ArtSpeechTransformer(V, A, embed_dim=d, num_heads=heads, num_layers=L, num_feat=nf)
+    # decoder layers start as deep copies (identical weights): perturb them so the fixture tells layers apart
+    with torch.no_grad():
+        for prm in model.decoder.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+        for m in model.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.7, 1.3)
+                m.bias.uniform_(-0.2, 0.2)
+
+    def loop_forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                     memory_key_padding_mask=None, **_):
+        out = tgt
+        for mod in self.layers:
+            out = mod(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                      tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask)
+        return out
+    model.decoder.forward = _t.MethodType(loop_forward, model.decoder)
+    model.eval()
+
+    lens = [7, 5]
+    batch = []
+    for i, l in enumerate(lens):
+        batch.append((f"s{i}", torch.randint(1, V, (l,)), torch.rand(l, A, 2, nf // 2), ["p"] * l, torch.rand(l, 1, 2, nf // 2),
+                      torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l)))
+    c = dataset.pad_sequence_transformer_collate_fn(batch)
+    tokens, targets, lengths = c[1], c[2], c[3]
+    src_kpm, tgt_kpm, src_mask, tgt_mask = c[8], c[9], c[10], c[11]
+    bs, T = tokens.shape
+    shifted = torch.cat([torch.zeros(bs, 1, A, nf), targets[:, 1:].reshape(bs, T - 1, A, nf)], dim=1)
+    captured = {}
+    hook = model.encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("enc", o.detach().clone()))
+    out_grad = model(tokens, shifted, src_key_padding_mask=src_kpm, tgt_key_padding_mask=tgt_kpm,
+                     src_attn_mask=src_mask, tgt_attn_mask=tgt_mask)          # grad enabled: standard encoder path
+    enc_grad = captured["enc"]
+    with torch.no_grad():                                                      # how evaluation runs it
+        out_nograd = model(tokens, shifted, src_key_padding_mask=src_kpm, tgt_key_padding_mask=tgt_kpm,
+                           src_attn_mask=src_mask, tgt_attn_mask=tgt_mask)
+        enc_nograd = captured["enc"]
+        gen = model.generate(tokens, src_key_padding_mask=src_kpm)
+        enc_gen = captured["enc"]
+    hook.remove()
+    arrays = dict(tokens=tokens.numpy(), targets=targets.numpy(), lengths=lengths.numpy(), shifted=shifted.numpy(),
+                  src_kpm=src_kpm.numpy(), tgt_kpm=tgt_kpm.numpy(), src_mask=src_mask.numpy(), tgt_mask=tgt_mask.numpy(),
+                  out_grad=out_grad.detach().numpy(), enc_grad=enc_grad.numpy(), out_nograd=out_nograd.numpy(),
+                  enc_nograd=enc_nograd.numpy(), gen=gen.numpy(), enc_gen=enc_gen.numpy(),
+                  cfg=np.array([V, A, d, heads, L, nf], dtype=np.int64))
+    arrays.update(sd_to_np("w.", model.state_dict()))
+    save("transformer_small", **arrays)
+    return dict(out_sum=float(out_nograd.sum()), gen_sum=float(gen.nansum()), n_keys=len(model.state_dict()),
+                enc_pad_zero_nograd=bool((enc_nograd[1, 5:] == 0).all()), enc_pad_zero_grad=bool((enc_grad[1, 5:] == 0).all()),
+                gen_nan=bool(gen.isnan().any()), params=sum(p.numel() for p in model.parameters()))
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)  # for `settings`, `helpers`
@@ -294,6 +357,9 @@ def main():
     gen_tract_variables(tv)
     gen_area_function(af)
     gen_host(helpers, dataset)
+    sys.modules["phoneme_to_articulation.encoder_decoder.models"] = models  # transformer/models.py:6 imports it by this name
+    tmod = _load("ref_transformer_models", "phoneme_to_articulation/transformer/models.py")
+    checks["transformer_small"] = gen_transformer(tmod, dataset)
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
     print(json.dumps(checks, indent=1))

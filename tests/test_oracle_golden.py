@@ -145,3 +145,19 @@ def test_torch_port_matches_reference_fixture():
     assert abs(loss - float(g["loss"])) < 1e-6
     assert relerr(port.p["linear.0.weight"].grad.numpy(), grads["linear.0.weight"]) < 1e-4
     assert relerr(port.rnn.weight_hh_l0.grad.numpy(), grads["rnn.weight_hh_l0"]) < 1e-4
+
+
+def test_transformer_oracle_matches_reference_fixture():
+    from oracle import transformer_oracle as TO
+    g = load_golden("transformer_small")
+    w, _ = split_wg(g)
+    cfg = tuple(int(v) for v in g["cfg"])
+    args = (g["tokens"], g["shifted"], g["src_mask"], g["tgt_mask"], g["src_kpm"], g["tgt_kpm"])
+    out = TO.forward(w, cfg, *args, grad_mode=True)            # standard encoder path
+    assert out.shape == g["out_grad"].shape and np.abs(out - g["out_grad"]).max() < 2e-6
+    out = TO.forward(w, cfg, *args, grad_mode=False)           # nested-tensor fast path: zeros at padded sources
+    assert np.abs(out - g["out_nograd"]).max() < 2e-6
+    assert np.abs(g["out_grad"] - g["out_nograd"]).max() > 1e-4  # the two modes really differ
+    gen = TO.generate(w, cfg, g["tokens"], g["src_kpm"])
+    # autoregressive feedback amplifies the fixture's own fp32 rounding frame after frame (fp64 oracle here)
+    assert gen.shape == g["gen"].shape and np.abs(gen - g["gen"]).max() < 2e-4
