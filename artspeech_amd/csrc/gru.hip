@@ -4,12 +4,15 @@
 //
 // The step is a dependent chain, so the design minimises per-step latency rather than bytes:
 //   * W_hh (3H x H fp32, 192 KB at H=128: more than the 160 KB LDS) is held in REGISTERS for the whole
-//     sequence, spread over the workgroup: 4 lanes per hidden unit, each lane owns a quarter of the
-//     reduction index of that unit's three gate rows (96 VGPRs at H=128);
-//   * h_{t-1} lives in LDS (double buffered, ONE barrier per step); a lane's quarter is interleaved in
-//     16-byte pieces (k = 16c + 4q + i) so the four lanes of a quad read four consecutive 16-B slots:
-//     every ds_read_b128 is a conflict-free broadcast; all reads of a step are issued before its FMAs;
-//   * the three gate dot products are finished with two DPP quad permutes (no LDS round trip);
+//     sequence, spread over the workgroup: LPU lanes per hidden unit, each lane owns 1/LPU of the
+//     reduction index of that unit's three gate rows (LPU = 4: 96 weight VGPRs per lane at H = 128, two
+//     waves per SIMD).  In-kernel cycle stamps (diagnostic build) put a step at ~1300 cycles: LDS read 130,
+//     FMAs + reduction ~430 (VALU issue shared by the SIMD's two waves), gate math ~200, LDS write + stores
+//     ~130 and ~430 waiting at the barrier for the partner wave -- VALU-issue bound, not memory bound;
+//   * h_{t-1} lives in LDS (double buffered, ONE barrier per step); a lane's share is interleaved in
+//     16-byte pieces (k = 4*LPU*c + 4q + i) so the lanes of a unit read consecutive 16-B slots:
+//     every ds_read_b128 is a conflict-free broadcast; reads are issued ahead of the FMAs in batches of 8;
+//   * the three gate dot products are finished with DPP quad permutes (no LDS round trip);
 //   * everything that does not depend on the recurrence (input projections, saved gates, upstream
 //     gradients) is loaded ONE STEP AHEAD, and the loop body is branch-free (redundant quad lanes store
 //     the same word) so that hipcc can count its loads and never waits for the step's own stores;
@@ -20,45 +23,30 @@
 // GEMMs over them (artspeech.hip).
 #include "as_common.h"
 
-#ifndef AS_ABL
-#define AS_ABL 0  // ablation switch for tools/ablate (0 = the real kernel)
-#endif
-// diagnostic build (AS_ABL == 6) only: cycle stamps around the segments of one recurrent step
-#if AS_ABL == 6
-#define AS_STAMP(i)                                                                  \
-    do {                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-        unsigned long long t__;                                                      \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-        seg[i] += t__ - tprev;                                                       \
-        tprev = t__;                                                                 \
-    } while (0)
-#else
-#define AS_STAMP(i)
-#endif
-
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// sum over the 4 lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
-__device__ __forceinline__ float quad_sum(float v) {
+// sum over the LPU (2 or 4) adjacent lanes that share a hidden unit: quad_perm [1,0,3,2] (then [2,3,0,1])
+template <int LPU>
+__device__ __forceinline__ float unit_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    if (LPU == 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
     return v;
 }
 
-template <int H, bool TRAIN, bool TOK>
-__global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
-                                                        long tok_stride, const float* __restrict__ w_hh,
-                                                        const float* __restrict__ b_hh, const int* __restrict__ lengths,
-                                                        int T, float* __restrict__ y, float* __restrict__ gates) {
-    constexpr int NC = H / 16;  // 16-float chunks of the reduction index; a lane owns 4 floats of each
+template <int H, int LPU, bool TRAIN, bool TOK>
+__global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
+                                                          long tok_stride, const float* __restrict__ w_hh,
+                                                          const float* __restrict__ b_hh, const int* __restrict__ lengths,
+                                                          int T, float* __restrict__ y, float* __restrict__ gates) {
+    constexpr int CW = 4 * LPU;   // floats of the reduction index covered by one ds_read_b128 of every lane of a unit
+    constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
+    constexpr int NT = LPU * H;   // threads
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
     extern __shared__ int tok_s[];  // TOK: token id of every frame of this utterance
     const int b = blockIdx.x, dir = blockIdx.y;
-    const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    const int tid = threadIdx.x, j = tid / LPU, q = tid % LPU;
     const int len = lengths[b];
 
     f32x2 w[3][NC * 2];  // packed pairs: v_pk_fma_f32 does two FMAs per lane per issue slot
@@ -68,7 +56,7 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(wd + (long)(g * H + j) * H + 16 * c + 4 * q);
+                const float4 v = *reinterpret_cast<const float4*>(wd + (long)(g * H + j) * H + CW * c + 4 * q);
                 w[g][2 * c] = f32x2{v.x, v.y};
                 w[g][2 * c + 1] = f32x2{v.z, v.w};
             }
@@ -76,10 +64,11 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     const float bh_r = b_hh[dir * 3 * H + j], bh_z = b_hh[dir * 3 * H + H + j], bh_n = b_hh[dir * 3 * H + 2 * H + j];
 
     // pad_packed_sequence: outputs of padded frames are exact zeros
-    for (int t = len + (tid / H); t < T; t += 4) y[((long)b * T + t) * 2 * H + dir * H + (tid % H)] = 0.f;
+    for (long i = (long)len * H + tid; i < (long)T * H; i += NT)
+        y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
-        for (int t = tid; t < len; t += 4 * H) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
+        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
     __syncthreads();
     if (len <= 0) return;
 
@@ -87,17 +76,13 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     // re-deriving them from t (the address arithmetic otherwise rivals the FMAs in issue slots).
     const int t0 = dir ? len - 1 : 0;
     const int dt = dir ? -1 : 1;
-    float* yb = y + dir * H + j;                               // + frame * 2H
-    float* gb = gates + (long)(dir * 4 + q) * H + j;           // + frame * 8H   (TRAIN)
-    const float* gib = gi + (long)dir * 3 * H + j;             // + row * 6H
-    long fr = (long)b * T + t0;                                // frame index of the current step
-    // select masks for the gate plane this lane stores (branch-free)
+    float* yb = y + dir * H + j;                     // + frame * 2H
+    float* gb = gates + (long)dir * 4 * H + j;       // + frame * 8H, planes r, z, n, hn at + plane * H   (TRAIN)
+    const float* gib = gi + (long)dir * 3 * H + j;   // + row * 6H
+    long fr = (long)b * T + t0;                      // frame index of the current step
+    // the LPU lanes of a unit hold identical gate values: lane q stores planes q, q + LPU, ... (branch-free selects)
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
 
-#if AS_ABL == 6  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tprev = c0;
-#endif
     float h = 0.f;
     float gr, gz, gn;
     {
@@ -108,90 +93,88 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     int t = t0;
     for (int s = 0; s < len; ++s) {
         const int cur = s & 1;
-        AS_STAMP(0);  // loop overhead / barrier exit
         // next step's input projection (independent of the recurrence): in flight during this step.
         // On the last step the look-ahead re-reads the current row (stays inside the sequence).
         const int adv = s + 1 < len ? dt : 0;
         const long rown = TOK ? (long)tok_s[t + adv] : fr + adv;
         const float* pn = gib + rown * 6 * H;
-        const float ngr = AS_ABL == 2 ? 0.1f : pn[0], ngz = AS_ABL == 2 ? 0.1f : pn[H], ngn = AS_ABL == 2 ? 0.1f : pn[2 * H];
+        const float ngr = pn[0], ngz = pn[H], ngn = pn[2 * H];
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
-        float4 hv[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) hv[c] = (AS_ABL == 4 && c > 0) ? hv[0] : hp[4 * c + q];
-        __builtin_amdgcn_sched_barrier(0);  // keep all reads ahead of the FMAs (hipcc otherwise pairs them 2 by 2)
-        AS_STAMP(1);  // prefetch issue + LDS reads landed
         f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < ((AS_ABL == 3 || AS_ABL == 4) ? 1 : NC); ++c) {
-            const f32x2 lo = {hv[c].x, hv[c].y}, hi = {hv[c].z, hv[c].w};
-            ar = __builtin_elementwise_fma(w[0][2 * c], lo, ar);
-            az = __builtin_elementwise_fma(w[1][2 * c], lo, az);
-            an = __builtin_elementwise_fma(w[2][2 * c], lo, an);
-            ar = __builtin_elementwise_fma(w[0][2 * c + 1], hi, ar);
-            az = __builtin_elementwise_fma(w[1][2 * c + 1], hi, az);
-            an = __builtin_elementwise_fma(w[2][2 * c + 1], hi, an);
+        for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their FMAs (hipcc otherwise pairs them 2 by 2)
+            float4 hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) hv[u] = hp[LPU * (c0 + u) + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) {
+                    const int c = c0 + u;
+                    const f32x2 lo = {hv[u].x, hv[u].y}, hi = {hv[u].z, hv[u].w};
+                    ar = __builtin_elementwise_fma(w[0][2 * c], lo, ar);
+                    az = __builtin_elementwise_fma(w[1][2 * c], lo, az);
+                    an = __builtin_elementwise_fma(w[2][2 * c], lo, an);
+                    ar = __builtin_elementwise_fma(w[0][2 * c + 1], hi, ar);
+                    az = __builtin_elementwise_fma(w[1][2 * c + 1], hi, az);
+                    an = __builtin_elementwise_fma(w[2][2 * c + 1], hi, an);
+                }
         }
-        const float sr = quad_sum(ar.x + ar.y), sz = quad_sum(az.x + az.y), sn = quad_sum(an.x + an.y);
-        asm volatile("" ::"v"(sr), "v"(sz), "v"(sn));
-        AS_STAMP(2);  // FMAs + quad reductions
-        const float r = AS_ABL == 5 ? gr + (sr + bh_r) : as_sigmoid(gr + (sr + bh_r));
-        const float z = AS_ABL == 5 ? 0.5f + 0.01f * (gz + (sz + bh_z)) : as_sigmoid(gz + (sz + bh_z));
+        const float sr = unit_sum<LPU>(ar.x + ar.y), sz = unit_sum<LPU>(az.x + az.y), sn = unit_sum<LPU>(an.x + an.y);
+        const float r = as_sigmoid(gr + (sr + bh_r));
+        const float z = as_sigmoid(gz + (sz + bh_z));
         const float hn = sn + bh_n;
-        const float n = AS_ABL == 5 ? 0.01f * (gn + r * hn) : as_tanh(gn + r * hn);
+        const float n = as_tanh(gn + r * hn);
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
-        asm volatile("" ::"v"(hnew));
-        AS_STAMP(3);  // gate math
-        // the 4 lanes of a quad hold identical values: all of them store (same word) -> no divergence
+        // the lanes of a unit hold identical values: all of them store (same word) -> no divergence
         hbuf[cur ^ 1][j] = hnew;
-        if (AS_ABL != 1) yb[fr * 2 * H] = hnew;
-        if (TRAIN && AS_ABL != 1) {
-            const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
-                           (__float_as_int(hn) & m3);
-            gb[fr * 8 * H] = __int_as_float(gv);
+        yb[fr * 2 * H] = hnew;
+        if (TRAIN) {
+            if (LPU == 4) {
+                const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
+                               (__float_as_int(hn) & m3);
+                gb[fr * 8 * H + q * H] = __int_as_float(gv);
+            } else {  // two lanes per unit: lane 0 stores r and n, lane 1 stores z and hn
+                const int ga = (__float_as_int(r) & m0) | (__float_as_int(z) & m1);
+                const int gc = (__float_as_int(n) & m0) | (__float_as_int(hn) & m1);
+                gb[fr * 8 * H + q * H] = __int_as_float(ga);
+                gb[fr * 8 * H + (2 + q) * H] = __int_as_float(gc);
+            }
         }
         gr = ngr; gz = ngz; gn = ngn;
         fr += dt;
         t += dt;
-        AS_STAMP(4);  // LDS write + global stores issued
         __syncthreads();
-        AS_STAMP(5);  // barrier
     }
-#if AS_ABL == 6
-    if (tid == 0 && b == 0 && dir == 0) {
-        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(gates);
-        dbg[0] = c1 - c0;
-        dbg[1] = r1 - r0;
-        for (int i = 0; i < 6; ++i) dbg[2 + i] = seg[i];
-    }
-#endif
 }
 
-template <int H>
-__global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        const float* __restrict__ gates, const float* __restrict__ w_hh,
-                                                        const int* __restrict__ lengths, int T, float* __restrict__ dgi,
-                                                        float* __restrict__ dgh) {
-    constexpr int NC = 3 * H / 16;
+template <int H, int LPU>
+__global__ __launch_bounds__(LPU * H) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ gates, const float* __restrict__ w_hh,
+                                                          const int* __restrict__ lengths, int T, float* __restrict__ dgi,
+                                                          float* __restrict__ dgh) {
+    constexpr int CW = 4 * LPU;
+    constexpr int NC = 3 * H / CW;
+    constexpr int NT = LPU * H;
     __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
     const int b = blockIdx.x, dir = blockIdx.y;
-    const int tid = threadIdx.x, k = tid >> 2, q = tid & 3;
+    const int tid = threadIdx.x, k = tid / LPU, q = tid % LPU;
     const int len = lengths[b];
 
-    // W_hh^T: this lane owns rows i = 16c + 4q + ii of column k (packed pairs for v_pk_fma_f32)
+    // W_hh^T: this lane owns rows i = CW*c + 4q + ii of column k (packed pairs for v_pk_fma_f32)
     f32x2 wt[NC * 2];
     {
         const float* wd = w_hh + (long)dir * 3 * H * H;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            wt[2 * c] = f32x2{wd[(long)(16 * c + 4 * q) * H + k], wd[(long)(16 * c + 4 * q + 1) * H + k]};
-            wt[2 * c + 1] = f32x2{wd[(long)(16 * c + 4 * q + 2) * H + k], wd[(long)(16 * c + 4 * q + 3) * H + k]};
+            wt[2 * c] = f32x2{wd[(long)(CW * c + 4 * q) * H + k], wd[(long)(CW * c + 4 * q + 1) * H + k]};
+            wt[2 * c + 1] = f32x2{wd[(long)(CW * c + 4 * q + 2) * H + k], wd[(long)(CW * c + 4 * q + 3) * H + k]};
         }
     }
     // zero the gradients of padded frames (rows feed time-batched GEMMs)
-    for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += 4 * H) {
+    for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += NT) {
         const long t = i / (3 * H), c = i % (3 * H);
         const long o = (((long)b * T + t) * 2 + dir) * 3 * H + c;
         dgi[o] = 0.f;
@@ -202,16 +185,18 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
     // walk opposite to the forward: forward dir t = len-1..0, reverse dir t = 0..len-1; running offsets
     const int t0 = dir ? 0 : len - 1;
     const int dt = dir ? 1 : -1;
-    const int sel = q < 2 ? q : 2;  // gate plane this lane stores (lanes 2 and 3 store the same words)
     const float* gtb = gates + (long)dir * 4 * H + k;   // + frame * 8H, planes at +0, +H, +2H, +3H
     const float* yb = y + dir * H + k;                   // + frame * 2H
     const float* dyb = dy + dir * H + k;                 // + frame * 2H
-    float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
-    float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
+    float* dgib = dgi + (long)dir * 3 * H + k;           // + frame * 6H + plane * H
+    float* dghb = dgh + (long)dir * 3 * H + k;
+    // Plane(s) stored by this lane.  LPU = 4: lane q stores plane min(q, 2) of both arrays (lanes 2, 3 the same
+    // words).  LPU = 2: lane 0 stores planes r (both arrays) and n of dgi; lane 1 planes z (both) and n of dgh.
+    const int sel = LPU == 4 ? (q < 2 ? q : 2) : q;
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q >= 2 ? -1 : 0;
     struct In { float r, z, n, hn, hprev, dyv; };
-    // h_{prev} of frame t is the output of frame t - dt... in FORWARD time: forward dir t-1, reverse dir t+1,
-    // i.e. the frame this backward walk visits NEXT (t + dt); zero beyond the sequence ends.
+    // h_{prev} of frame t is the output of the frame this backward walk visits NEXT (t + dt): forward dir t-1,
+    // reverse dir t+1; zero beyond the sequence ends.
     auto load = [&](long fr, bool has_prev) {
         In v;
         const float* gp = gtb + fr * 8 * H;
@@ -238,21 +223,31 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
         const float g_z = dz * z * (1.f - z);
         const float g_hn = dnt * r;
         // planes r, z, n of d/d(W_ih x + b_ih) and d/d(W_hh h + b_hh): they differ in the n plane only
-        const int rz = (__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1);
-        const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
-        const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
-        gbuf[cur][sel * H + k] = vh;
-        dgib[fr * 6 * H] = vi;
-        dghb[fr * 6 * H] = vh;
+        if (LPU == 4) {
+            const int rz = (__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1);
+            const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
+            const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
+            gbuf[cur][sel * H + k] = vh;
+            dgib[fr * 6 * H + sel * H] = vi;
+            dghb[fr * 6 * H + sel * H] = vh;
+        } else {
+            const float rz = __int_as_float((__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1));
+            const float nn = __int_as_float((__float_as_int(dnt) & m0) | (__float_as_int(g_hn) & m1));
+            gbuf[cur][sel * H + k] = rz;
+            gbuf[cur][2 * H + k] = g_hn;  // both lanes write the same word
+            dgib[fr * 6 * H + sel * H] = rz;
+            dghb[fr * 6 * H + sel * H] = rz;
+            (q == 0 ? dgib : dghb)[fr * 6 * H + 2 * H] = nn;
+        }
         __syncthreads();
         const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-        for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their 32 FMAs on 4 chains
+        for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their FMAs
             float4 gv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (c0 + u < NC) gv[u] = gq[4 * (c0 + u) + q];
+                if (c0 + u < NC) gv[u] = gq[LPU * (c0 + u) + q];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
                     a1 = __builtin_elementwise_fma(wt[2 * c + 1], f32x2{gv[u].z, gv[u].w}, a1);
                 }
         }
-        const float acc = quad_sum((a0.x + a0.y) + (a1.x + a1.y));
+        const float acc = unit_sum<LPU>((a0.x + a0.y) + (a1.x + a1.y));
         dh = dht * z + acc;
         cur_in = nxt;
         fr += dt;
@@ -270,6 +265,12 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
         // precede the barrier above, so one barrier per step suffices.
     }
 }
+
+// Lanes per hidden unit.  Both layouts are built; measured at H = 128, B = 32, T = 200 (tools/bench_gru.py):
+// LPU = 4 (512 threads, two waves per SIMD): forward 0.55 us/step, backward 0.70; LPU = 2 (256 threads, one
+// wave per SIMD, 252 VGPRs): 0.56 / 0.77 -- the second wave hides the first one's LDS / DPP / transcendental
+// latencies about as well as halving the redundant gate math helps, so the 4-lane layout stays.
+constexpr int lpu_of(int) { return 4; }
 
 }  // namespace
 
@@ -282,9 +283,9 @@ extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
     const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
-#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                      \
-    hipLaunchKernelGGL((gru_fwd_kernel<HH, TR, TK>), grid, dim3(4 * HH), shm, st, gi, tokens, (long)tok_stride, w_hh, \
-                       b_hh, lengths, T, y, gates)
+#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
+    hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens,       \
+                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates)
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
     else if (gates) AS_GRU_LAUNCH(HH, true, false);         \
@@ -311,14 +312,18 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: B=%d T=%d", B, T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
+#define AS_GRU_BWD(HH)                                                                                              \
+    hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
+                       T, dgi, dgh)
     switch (H) {
-        case 32: hipLaunchKernelGGL((gru_bwd_kernel<32>), grid, dim3(128), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh); break;
-        case 64: hipLaunchKernelGGL((gru_bwd_kernel<64>), grid, dim3(256), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh); break;
-        case 128: hipLaunchKernelGGL((gru_bwd_kernel<128>), grid, dim3(512), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh); break;
+        case 32: AS_GRU_BWD(32); break;
+        case 64: AS_GRU_BWD(64); break;
+        case 128: AS_GRU_BWD(128); break;
         default:
             as_set_error("as_gru_bidir_bwd: hidden size %d not in {32, 64, 128}", H);
             return AS_ERR_UNSUPPORTED;
     }
+#undef AS_GRU_BWD
     AS_LAUNCH_CHECK("as_gru_bidir_bwd");
     return 0;
 }

@@ -49,12 +49,3 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     us = 1e3 * e0.elapsed_time(e1) / iters
     print(f"{os.environ.get('ARTSPEECH_LIB', 'default')[-24:]:24s} gru {name}: {us:8.1f} us/launch  {us / T * 1e3:7.1f} ns/step", flush=True)
 
-if "abl6" in os.environ.get("ARTSPEECH_LIB", ""):
-    for _ in range(200):
-        fwd()
-    torch.cuda.synchronize()
-    dbg = gates.view(-1)[:16].view(torch.int64).cpu()
-    print("segments (cycles/step): " + ", ".join(f"{n} {int(dbg[2 + i]) / T:.0f}" for i, n in enumerate(
-        ["loop/exit", "prefetch+LDS read", "FMA+reduce", "gates", "stores+LDS write", "barrier"])), flush=True)
-    print(f"in-kernel: {int(dbg[0])} shader cycles over {int(dbg[1])} x 10 ns => clock {int(dbg[0]) / int(dbg[1]) * 100:.0f} MHz, "
-          f"{int(dbg[0]) / T:.0f} cycles/step", flush=True)
