@@ -77,6 +77,11 @@ PROTOTYPES = {
     "as_fold_ln": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "as_attn_softmax": (_I32, [_P, _I64, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "as_embed_posenc": (_I32, [_P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "as_attn_softmax_bwd": (_I32, [_P, _P, _I64, _I32, _I32, _F, _P]),
+    "as_group_reduce": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P]),
+    "as_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "as_unfold_ln": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "as_relu_bwd": (_I32, [_P, _P, _P, _I64, _P]),
     "as_add": (_I32, [_P, _P, _P, _I64, _P]),
     "as_row_scale": (_I32, [_P, _P, _P, _I64, _I32, _P]),
     "as_set_overlap": (None, [_I32]),

@@ -8,7 +8,8 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // row length <= 64 * MAXC
+constexpr int MAXC = 8;   // row length <= 64 * MAXC for the head kernels (register resident rows)
+constexpr int MAXCW = 44;  // wide rows (transformer: LayerNorm over 10*d / A*d features)
 
 // ---- x_hat = (x - mean) * rstd over the last dim (biased variance, eps) -------------------------
 __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restrict__ x, float* __restrict__ xhat,
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restr
 
 // ---- dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) * (relu_src > 0) ------------------------
 // dy and dx may alias (in-place): a lane reads all its elements before it writes any.
+template <int MW>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ relu_src, float* dx,
@@ -55,10 +57,10 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
     if (row >= rows) return;
     const float* dyr = dy + row * D;
     const float* xr = xhat + row * D;
-    float g[MAXC], h[MAXC];
+    float g[MW], h[MW];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MW; ++c) {
         const int i = lane + 64 * c;
         g[c] = i < D ? dyr[i] : 0.f;
         h[c] = i < D ? xr[i] : 0.f;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
     const float rs = rstd[row];
     float* o = dx + row * D;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MW; ++c) {
         const int i = lane + 64 * c;
         if (i < D) {
             float v = rs * (g[c] - m1 - h[c] * m2);
@@ -370,6 +372,56 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     }
 }
 
+// ---- softmax backward over the last dim, in place on dP: dS = P * (dP - sum_k dP*P) * scale --------
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows,
+                                                               int Tk, float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pr = p + row * Tk;
+    float* dr = dp + row * Tk;
+    constexpr int MAXW = 16;
+    float pv[MAXW], dv[MAXW];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int k = lane + 64 * c;
+        pv[c] = k < Tk ? pr[k] : 0.f;
+        dv[c] = k < Tk ? dr[k] : 0.f;
+        s += pv[c] * dv[c];
+    }
+    s = as_wave_sum(s);
+#pragma unroll
+    for (int c = 0; c < MAXW; ++c) {
+        const int k = lane + 64 * c;
+        if (k < Tk) dr[k] = pv[c] * (dv[c] - s) * scale;
+    }
+}
+
+// ---- dst[c][i] = sum over groups g with src[g] == c of part[g][i]   (i over `len` contiguous floats) ---
+// deterministic: groups are visited in index order.  grid.y = channel, grid.x over the row.
+__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ part, const int* __restrict__ src, int G,
+                                                           long len, float* __restrict__ dst) {
+    const int c = blockIdx.y;
+    const long n4 = len / 4;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < G; ++g)
+            if (src[g] == c) {
+                const float4 v = reinterpret_cast<const float4*>(part + (long)g * len)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        reinterpret_cast<float4*>(dst + (long)c * len)[i] = acc;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < len; i += stride) {
+        float acc = 0.f;
+        for (int g = 0; g < G; ++g)
+            if (src[g] == c) acc += part[(long)g * len + i];
+        dst[(long)c * len + i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_posenc_kernel(const int64_t* __restrict__ tokens, long tok_stride,
                                                            const float* __restrict__ table, const float* __restrict__ pe,
                                                            float* __restrict__ out, long rows, int T, int D) {
@@ -406,8 +458,11 @@ int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D,
 }
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
                      int D, hipStream_t st) {
-    AS_REQUIRE(D > 0 && D <= 64 * MAXC, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXC);
-    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
+    AS_REQUIRE(D > 0 && D <= 64 * MAXCW, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXCW);
+    if (D <= 64 * MAXC)
+        hipLaunchKernelGGL(normalize_bwd_kernel<MAXC>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
+    else
+        hipLaunchKernelGGL(normalize_bwd_kernel<MAXCW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
     AS_LAUNCH_CHECK("normalize_bwd");
     return 0;
 }
@@ -490,6 +545,47 @@ extern "C" int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk,
                        scale, attn_mask, key_padding_mask);
     AS_LAUNCH_CHECK("as_attn_softmax");
     return 0;
+}
+
+extern "C" int as_attn_softmax_bwd(const float* probs, float* dprobs, int64_t Z, int32_t Tq, int32_t Tk, float scale,
+                                   void* stream) {
+    AS_REQUIRE(probs && dprobs && Z > 0 && Tq > 0 && Tk > 0, AS_ERR_BAD_ARG, "as_attn_softmax_bwd: bad argument");
+    AS_REQUIRE(Tk <= 1024, AS_ERR_UNSUPPORTED, "as_attn_softmax_bwd: Tk=%d > 1024", Tk);
+    const long rows = (long)Z * Tq;
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs, rows, Tk,
+                       scale);
+    AS_LAUNCH_CHECK("as_attn_softmax_bwd");
+    return 0;
+}
+
+extern "C" int as_group_reduce(const float* part, const int32_t* src, int32_t G, int32_t C, int64_t len, float* dst, void* stream) {
+    AS_REQUIRE(part && src && dst && G > 0 && C > 0 && len > 0, AS_ERR_BAD_ARG, "as_group_reduce: bad argument");
+    AS_REQUIRE((reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && len % 4 == 0,
+               AS_ERR_BAD_ARG, "as_group_reduce: buffers must be 16-byte aligned and len a multiple of 4");
+    long bx = (len / 4 + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(group_reduce_kernel, dim3((int)bx, C), dim3(256), 0, (hipStream_t)stream, part, src, G, (long)len, dst);
+    AS_LAUNCH_CHECK("as_group_reduce");
+    return 0;
+}
+
+extern "C" int as_layernorm_bwd(const float* dxhat, const float* xhat, const float* rstd, const float* relu_src, float* dx,
+                                int64_t rows, int32_t D, void* stream) {
+    AS_REQUIRE(dxhat && xhat && rstd && dx && rows > 0 && D > 0, AS_ERR_BAD_ARG, "as_layernorm_bwd: bad argument");
+    return as_normalize_bwd(dxhat, xhat, rstd, relu_src, dx, (long)rows, D, (hipStream_t)stream);
+}
+
+extern "C" int as_unfold_ln(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
+                            float* dgamma, float* dbeta, int32_t heads, int32_t R, int32_t K, void* stream) {
+    AS_REQUIRE(dWf && dbf && W && gamma && beta && dW && dgamma && dbeta && heads > 0 && R > 0 && K > 0, AS_ERR_BAD_ARG,
+               "as_unfold_ln: bad argument");
+    return as_unfold(dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, heads, R, K, (hipStream_t)stream);
+}
+
+extern "C" int as_relu_bwd(const float* g, const float* act, float* dst, int64_t n, void* stream) {
+    AS_REQUIRE(g && act && dst && n > 0, AS_ERR_BAD_ARG, "as_relu_bwd: bad argument");
+    return as_relu_mask(g, act, dst, (long)n, (hipStream_t)stream);
 }
 
 extern "C" int as_embed_posenc(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pe, float* out,

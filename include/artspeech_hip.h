@@ -230,6 +230,25 @@ int as_fold_ln(const float* W, const float* gamma, const float* beta, const floa
 int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk, int32_t heads, int32_t B, float scale,
                     const float* attn_mask, const float* key_padding_mask, void* stream);
 
+/* Backward of as_attn_softmax, in place on dprobs: dS = P * (dP - sum_k dP * P) * scale. */
+int as_attn_softmax_bwd(const float* probs, float* dprobs, int64_t Z, int32_t Tq, int32_t Tk, float scale, void* stream);
+
+/* dst[c][:] = sum over groups g with src[g] == c of part[g][:] (rows of `len` floats; deterministic order): folds
+ * the per-block input gradients of a grouped GEMM back onto the channels the blocks read. */
+int as_group_reduce(const float* part, const int32_t* src, int32_t G, int32_t C, int64_t len, float* dst, void* stream);
+
+/* Backward of the affine-free LayerNorm: dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), optionally
+ * times the ReLU mask (relu_src > 0).  dxhat and dx may alias.  Rows up to 512 wide (wider: D <= 2816). */
+int as_layernorm_bwd(const float* dxhat, const float* xhat, const float* rstd, const float* relu_src, float* dx, int64_t rows,
+                     int32_t D, void* stream);
+
+/* Backward of as_fold_ln: (dWf, dbf) -> dW = dWf.diag(gamma) + dbf beta^T, dgamma, dbeta (db == dbf). */
+int as_unfold_ln(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
+                 float* dgamma, float* dbeta, int32_t heads, int32_t R, int32_t K, void* stream);
+
+/* dst[i] = act[i] > 0 ? g[i] : 0 */
+int as_relu_bwd(const float* g, const float* act, float* dst, int64_t n, void* stream);
+
 /* out[m][:] = table[tokens[m]][:] + pe[m % T][:]  (Embedding + PositionalEncoding, transformer/models.py:9-34,368-369);
  * table == NULL: out[m][:] += pe[m % T][:] in place. */
 int as_embed_posenc(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pe, float* out,

@@ -293,6 +293,8 @@ def gen_transformer(tmod, dataset):
     out_grad = model(tokens, shifted, src_key_padding_mask=src_kpm, tgt_key_padding_mask=tgt_kpm,
                      src_attn_mask=src_mask, tgt_attn_mask=tgt_mask)          # grad enabled: standard encoder path
     enc_grad = captured["enc"]
+    dout = torch.rand_like(out_grad)
+    (out_grad * dout).sum().backward()                                         # gradients of every parameter
     with torch.no_grad():                                                      # how evaluation runs it
         out_nograd = model(tokens, shifted, src_key_padding_mask=src_kpm, tgt_key_padding_mask=tgt_kpm,
                            src_attn_mask=src_mask, tgt_attn_mask=tgt_mask)
@@ -304,8 +306,9 @@ def gen_transformer(tmod, dataset):
                   src_kpm=src_kpm.numpy(), tgt_kpm=tgt_kpm.numpy(), src_mask=src_mask.numpy(), tgt_mask=tgt_mask.numpy(),
                   out_grad=out_grad.detach().numpy(), enc_grad=enc_grad.numpy(), out_nograd=out_nograd.numpy(),
                   enc_nograd=enc_nograd.numpy(), gen=gen.numpy(), enc_gen=enc_gen.numpy(),
-                  cfg=np.array([V, A, d, heads, L, nf], dtype=np.int64))
+                  dout=dout.numpy(), cfg=np.array([V, A, d, heads, L, nf], dtype=np.int64))
     arrays.update(sd_to_np("w.", model.state_dict()))
+    arrays.update({"g." + k: p.grad.numpy() for k, p in model.named_parameters()})
     save("transformer_small", **arrays)
     return dict(out_sum=float(out_nograd.sum()), gen_sum=float(gen.nansum()), n_keys=len(model.state_dict()),
                 enc_pad_zero_nograd=bool((enc_nograd[1, 5:] == 0).all()), enc_pad_zero_grad=bool((enc_grad[1, 5:] == 0).all()),

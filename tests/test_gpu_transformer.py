@@ -42,7 +42,7 @@ def test_forward_matches_reference_fixture(small, dev):
     err = np.abs(out.cpu().numpy() - g["out_nograd"])
     assert (err <= 1e-4 * np.abs(g["out_nograd"]) + 1e-6).all(), err.max()
     out = model(src, tgt, **args)  # grad enabled + trainable parameters: standard encoder path (no zeroing)
-    err = np.abs(out.cpu().numpy() - g["out_grad"])
+    err = np.abs(out.detach().cpu().numpy() - g["out_grad"])
     assert (err <= 1e-4 * np.abs(g["out_grad"]) + 1e-6).all(), err.max()
 
 
@@ -51,7 +51,7 @@ def test_encoder_matches_reference_fixture(small, dev):
     src, kpm = _t(g["tokens"], dev, torch.int64), _t(g["src_kpm"], dev)
     for zero, key in ((True, "enc_nograd"), (False, "enc_grad")):
         mem = model._encode(src, kpm, zero_padded=zero).view(g[key].shape)
-        assert np.abs(mem.cpu().numpy() - g[key]).max() < 5e-6, key
+        assert np.abs(mem.detach().cpu().numpy() - g[key]).max() < 5e-6, key
 
 
 def test_generate_matches_reference_fixture(small, dev):
@@ -101,6 +101,120 @@ def test_medium_config_vs_oracle(dev):
                     src_attn_mask=c[10].to(dev), tgt_attn_mask=c[11].to(dev))
         ref = TO.forward(sd, (V, A, d, h, L, nf), tokens.numpy(), shifted.numpy(), c[10].numpy(), c[11].numpy(), c[8].numpy(),
                          c[9].numpy(), grad_mode=grad_mode)
-        err = np.abs(out.cpu().numpy() - ref)
+        err = np.abs(out.detach().cpu().numpy() - ref)
         assert (err <= 1e-4 * np.abs(ref) + 1e-6).all(), (grad_mode, err.max())
     model.set_encoder_grad_mode(None)
+
+
+# ------------------------------------------------------------------------------------------- training (backward)
+def test_backward_matches_reference_fixture(small, dev):
+    """eval mode + gradient tracking (dropout off, standard encoder path): d(sum(out * dout)) / d(every parameter)
+    against the gradients the reference's autograd produced for the same weights and inputs."""
+    model, g, _ = small
+    _, grads = split_wg(g)
+    model.zero_grad()
+    args = dict(src_key_padding_mask=_t(g["src_kpm"], dev), tgt_key_padding_mask=_t(g["tgt_kpm"], dev),
+                src_attn_mask=_t(g["src_mask"], dev), tgt_attn_mask=_t(g["tgt_mask"], dev))
+    out = model(_t(g["tokens"], dev, torch.int64), _t(g["shifted"], dev), **args)
+    assert np.abs(out.detach().cpu().numpy() - g["out_grad"]).max() < 5e-6
+    (out * _t(g["dout"], dev)).sum().backward()
+    gv = model.named_grad_views()
+    assert set(gv) == set(grads), set(gv) ^ set(grads)
+    worst = ("", 0.0)
+    for k, ref in grads.items():
+        got = gv[k].cpu().numpy()
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, (k, float(err)), key=lambda t: t[1])
+        assert err < 1e-3, (k, err)
+    print("worst gradient relative error:", worst)
+    model.zero_grad()
+
+
+def test_grouped_linear_and_attention_ops_vs_torch(dev):
+    from artspeech_amd.phoneme_to_articulation.transformer.ops import Attention, FoldLN, GroupedLinear, LayerNormAffine, Normalize
+    torch.manual_seed(0)
+    C_, R, K, G, N = 3, 40, 16, 5, 24
+    x = torch.randn(C_, R, K, device=dev, requires_grad=True)
+    W = torch.randn(G, N, K, device=dev, requires_grad=True)
+    b = torch.randn(G, N, device=dev, requires_grad=True)
+    src = (2, 0, 0, 1, 2)
+    out = GroupedLinear.apply(x, W, b, src, True)
+    ref = torch.relu(torch.einsum("grk,gnk->grn", x[list(src)], W) + b[:, None])
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+    go = torch.randn_like(out)
+    gx, gW, gb = torch.autograd.grad(out, (x, W, b), go)
+    rx, rW, rb = torch.autograd.grad(ref, (x, W, b), go)
+    for a_, r_ in ((gx, rx), (gW, rW), (gb, rb)):
+        assert torch.allclose(a_, r_, rtol=1e-4, atol=2e-4), (a_ - r_).abs().max()
+    # attention: G blocks, B sequences, T != Tk, additive float masks
+    G, B, T, Tk, d, h = 2, 3, 6, 9, 16, 4
+    Q = torch.randn(G, B * T, d, device=dev, requires_grad=True)
+    Kt = torch.randn(G, B * Tk, d, device=dev, requires_grad=True)
+    V = torch.randn(G, B * Tk, d, device=dev, requires_grad=True)
+    am = torch.zeros(B, T, Tk, device=dev).masked_fill(torch.rand(B, T, Tk, device=dev) < 0.2, float("-inf"))
+    am[:, :, 0] = 0  # keep one visible key per row
+    kpm = torch.zeros(B, Tk, device=dev)
+    kpm[1, 6:] = float("-inf")
+    out = Attention.apply(Q, Kt, V, am, kpm, B, h)
+
+    def ref_attn(Q, Kt, V):
+        q = Q.view(G, B, T, h, d // h).permute(0, 1, 3, 2, 4)
+        k = Kt.view(G, B, Tk, h, d // h).permute(0, 1, 3, 2, 4)
+        v = V.view(G, B, Tk, h, d // h).permute(0, 1, 3, 2, 4)
+        s = q @ k.transpose(-1, -2) / (d // h) ** 0.5 + am[None, :, None] + kpm[None, :, None, None]
+        return (torch.softmax(s, -1) @ v).permute(0, 1, 3, 2, 4).reshape(G, B * T, d)
+    ref = ref_attn(Q, Kt, V)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
+    go = torch.randn_like(out)
+    for a_, r_ in zip(torch.autograd.grad(out, (Q, Kt, V), go), torch.autograd.grad(ref, (Q, Kt, V), go)):
+        assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-5), (a_ - r_).abs().max()
+    # LayerNorm pieces
+    x = torch.randn(7, 50, device=dev, requires_grad=True)
+    r = torch.randn(7, 50, device=dev, requires_grad=True)
+    gm = torch.rand(50, device=dev, requires_grad=True)
+    bt = torch.randn(50, device=dev, requires_grad=True)
+    y = LayerNormAffine.apply(x, r, gm, bt)
+    yr = torch.nn.functional.layer_norm(x + r, (50,), gm, bt)
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5)
+    go = torch.randn_like(y)
+    for a_, r_ in zip(torch.autograd.grad(y, (x, r, gm, bt), go), torch.autograd.grad(yr, (x, r, gm, bt), go)):
+        assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-5)
+    xh = Normalize.apply(x)
+    assert torch.allclose(xh, torch.nn.functional.layer_norm(x, (50,)), rtol=1e-5, atol=1e-5)
+    Wl = torch.randn(2, 5, 50, device=dev, requires_grad=True)
+    g2 = torch.rand(2, 50, device=dev, requires_grad=True)
+    b2 = torch.randn(2, 50, device=dev, requires_grad=True)
+    bb = torch.randn(2, 5, device=dev, requires_grad=True)
+    Wf, bf = FoldLN.apply(Wl, g2, b2, bb)
+    Wr, br = Wl * g2[:, None], bb + torch.einsum("grk,gk->gr", Wl, b2)
+    assert torch.allclose(Wf, Wr) and torch.allclose(bf, br, rtol=1e-5, atol=1e-5)
+    gW, gbv = torch.randn_like(Wf), torch.randn_like(bf)
+    for a_, r_ in zip(torch.autograd.grad((Wf, bf), (Wl, g2, b2, bb), (gW, gbv)), torch.autograd.grad((Wr, br), (Wl, g2, b2, bb), (gW, gbv))):
+        assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-4)
+
+
+def test_transformer_training_step_decreases_loss(dev):
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(0)
+    V, A, d, h, L, nf = 12, 3, 32, 4, 2, 100
+    model = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    lens = [14, 10, 6]
+    batch = [(f"s{i}", torch.randint(1, V, (l,)), torch.rand(l, A, 2, nf // 2), ["p"] * l, torch.rand(l, 1, 2, nf // 2),
+              torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l)) for i, l in enumerate(lens)]
+    c = pad_sequence_transformer_collate_fn(batch)
+    tokens, targets, lengths = c[1].to(dev), c[2].to(dev), c[3]
+    B, T = tokens.shape
+    shifted = torch.cat([torch.zeros(B, 1, A, nf, device=dev), targets[:, 1:].reshape(B, T - 1, A, nf)], dim=1)
+    kw = dict(src_key_padding_mask=c[8].to(dev), tgt_key_padding_mask=c[9].to(dev), src_attn_mask=c[10].to(dev), tgt_attn_mask=c[11].to(dev))
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        out = model(tokens, shifted, **kw)
+        loss = masked_euclidean_loss(out, targets, lengths)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.02, losses
