@@ -36,3 +36,29 @@ with torch.no_grad():
 flops = 2 * 0.503e9 * B * T  # ~0.50 GMAC per frame forward
 print(f"forward B={B} T={T}: {dt * 1e3:.1f} ms  -> {B * T / dt:.0f} frames/s, {flops / dt / 1e12:.1f} TFLOP/s (fp32 MFMA peak 157.3); "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+
+# ---- training step: forward + masked Euclidean loss + backward (no optimizer), dropout 0 like the parity runs
+from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss  # noqa: E402
+model.eval()  # deterministic (the encoder's library-default dropout 0.1 only acts in train mode); grads still flow
+lengths = c[3]
+torch.cuda.reset_peak_memory_stats()
+
+
+def step():
+    for p_ in model.parameters():
+        p_.grad = None
+    out = model(tokens, shifted, **kw)
+    loss = masked_euclidean_loss(out, targets, lengths)
+    loss.backward()
+    return loss
+
+
+loss = step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / iters
+print(f"fwd+bwd B={B} T={T}: {dt * 1e3:.1f} ms -> {B * T / dt:.0f} frames/s, {3 * flops / dt / 1e12:.1f} TFLOP/s; loss {loss.item():.5f}; "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
