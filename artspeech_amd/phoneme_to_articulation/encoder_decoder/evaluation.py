@@ -15,7 +15,6 @@ import numpy as np
 import torch
 
 from ... import metrics as root_metrics
-from ...helpers import make_padding_mask
 from ...tract_variables import REQUIRED_ARTICULATORS, TV_NAMES, UPPER_INCISOR, tract_variables_batched
 from ..metrics import masked_euclidean_loss
 
@@ -45,61 +44,71 @@ def _write_tract_variables(save_to, sentences_ids, frame_ids, outputs, targets, 
             writer.writerows(rows)
 
 
+class _Accumulator:
+    """Per-articulator metric lists + file outputs shared by run_test and run_transformer_test."""
+
+    def __init__(self, articulators, epoch_outputs_dir, device):
+        self.articulators, self.dir, self.device = list(articulators), epoch_outputs_dir, device
+        n = len(self.articulators)
+        self.losses = []
+        self.euclid, self.p2cp = [[] for _ in range(n)], [[] for _ in range(n)]
+        self.x_corrs, self.y_corrs = [[] for _ in range(n)], [[] for _ in range(n)]
+
+    def add(self, loss, outputs, targets, lengths, sentences_ids, sentence_frames, phonemes, reference_arrays):
+        device, arts = self.device, self.articulators
+        with torch.no_grad():
+            p2cp_bta = root_metrics.p2cp_distance(outputs, targets)            # (B, T, A)
+            med_bta = root_metrics.euclidean_distance(outputs, targets)        # (B, T, A)
+        self.losses.append(float(loss))
+        for b, length in enumerate(lengths):
+            length = int(length)
+            pv, mv = p2cp_bta[b, :length].cpu().numpy(), med_bta[b, :length].cpu().numpy()
+            # NOTE as the reference (:68-74): .mean(dim=1) collapses the frames of the single utterance
+            xc, yc = root_metrics.pearsons_correlation(outputs[b:b + 1, :length], targets[b:b + 1, :length])
+            xc, yc = xc.mean(dim=-1)[0].cpu().numpy(), yc.mean(dim=-1)[0].cpu().numpy()
+            for i in range(len(arts)):
+                self.x_corrs[i].append(float(xc[i]))
+                self.y_corrs[i].append(float(yc[i]))
+                self.p2cp[i].append(float(pv[:, i].mean()))
+                self.euclid[i].append(float(mv[:, i].mean()))
+        # upper incisor = reference of the coordinate system: injected for the tract variables (:93-109)
+        if UPPER_INCISOR not in arts:
+            tv_articulators = sorted(arts + [UPPER_INCISOR])
+            ref_idx = tv_articulators.index(UPPER_INCISOR)
+            ref = reference_arrays[:, :outputs.shape[1]].to(device)
+            outputs = torch.cat([outputs[:, :, :ref_idx], ref, outputs[:, :, ref_idx:]], dim=2)
+            targets = torch.cat([targets[:, :, :ref_idx], ref, targets[:, :, ref_idx:]], dim=2)
+        else:
+            tv_articulators = arts
+        if all(a in tv_articulators for a in REQUIRED_ARTICULATORS) and outputs.shape[-1] >= 50:
+            _write_tract_variables(self.dir, sentences_ids, sentence_frames, outputs, targets, lengths, phonemes, tv_articulators)
+
+    def info(self, dataset_config):
+        to_mm = dataset_config.RES * dataset_config.PIXEL_SPACING
+        info = {"loss": float(np.mean(self.losses))}
+        info.update({
+            art: {
+                "x_corr": float(np.mean(self.x_corrs[i])), "y_corr": float(np.mean(self.y_corrs[i])),
+                "p2cp": float(np.mean(self.p2cp[i])), "p2cp_mm": float(np.mean(self.p2cp[i]) * to_mm),
+                "med": float(np.mean(self.euclid[i])), "med_mm": float(np.mean(self.euclid[i]) * to_mm),
+            }
+            for i, art in enumerate(self.articulators)
+        })
+        return info
+
+
 def run_test(epoch, model, dataloader, criterion, outputs_dir, articulators, device=None, regularize_out=False):
     if device is None:
         device = torch.device("cuda")
     epoch_outputs_dir = os.path.join(outputs_dir, str(epoch))
     os.makedirs(epoch_outputs_dir, exist_ok=True)
     model.eval()
-    dataset_config = dataloader.dataset.dataset_config
-    n_art = len(articulators)
-    losses = []
-    euclid = [[] for _ in articulators]
-    p2cp = [[] for _ in articulators]
-    x_corrs = [[] for _ in articulators]
-    y_corrs = [[] for _ in articulators]
+    acc = _Accumulator(articulators, epoch_outputs_dir, device)
     for sentences_ids, sentences, targets, lengths, phonemes, reference_arrays, sentence_frames, _ in dataloader:
         sentences, targets = sentences.to(device), targets.to(device)
         with torch.no_grad():
             outputs = model(sentences, lengths)
             targets = targets[:, :outputs.shape[1]]
             loss = masked_euclidean_loss(outputs, targets, lengths)  # criterion + padding mask + mean (:56-63)
-            mask = make_padding_mask(lengths).to(device)                       # (B, T)
-            p2cp_bta = root_metrics.p2cp_distance(outputs, targets)            # (B, T, A)
-            med_bta = root_metrics.euclidean_distance(outputs, targets)        # (B, T, A)
-        losses.append(loss.item())
-        for b, length in enumerate(lengths):
-            length = int(length)
-            # per-frame values of the valid frames (the reference extends its lists frame by frame, :80-84)
-            pv, mv = p2cp_bta[b, :length].cpu().numpy(), med_bta[b, :length].cpu().numpy()
-            # NOTE as the reference (:68-74): .mean(dim=1) collapses the frames of the single utterance
-            xc, yc = root_metrics.pearsons_correlation(outputs[b:b + 1, :length], targets[b:b + 1, :length])
-            xc, yc = xc.mean(dim=-1)[0].cpu().numpy(), yc.mean(dim=-1)[0].cpu().numpy()
-            for i in range(n_art):
-                x_corrs[i].append(float(xc[i]))
-                y_corrs[i].append(float(yc[i]))
-                p2cp[i].append(float(pv[:, i].mean()))
-                euclid[i].append(float(mv[:, i].mean()))
-        # upper incisor = reference of the coordinate system: injected for the tract variables (:93-109)
-        if UPPER_INCISOR not in articulators:
-            tv_articulators = sorted(list(articulators) + [UPPER_INCISOR])
-            ref_idx = tv_articulators.index(UPPER_INCISOR)
-            ref = reference_arrays[:, :outputs.shape[1]].to(device)
-            outputs = torch.cat([outputs[:, :, :ref_idx], ref, outputs[:, :, ref_idx:]], dim=2)
-            targets = torch.cat([targets[:, :, :ref_idx], ref, targets[:, :, ref_idx:]], dim=2)
-        else:
-            tv_articulators = list(articulators)
-        if all(a in tv_articulators for a in REQUIRED_ARTICULATORS) and outputs.shape[-1] >= 50:
-            _write_tract_variables(epoch_outputs_dir, sentences_ids, sentence_frames, outputs, targets, lengths, phonemes,
-                                   tv_articulators)
-    to_mm = dataset_config.RES * dataset_config.PIXEL_SPACING
-    info = {"loss": float(np.mean(losses))}
-    info.update({
-        art: {
-            "x_corr": float(np.mean(x_corrs[i])), "y_corr": float(np.mean(y_corrs[i])),
-            "p2cp": float(np.mean(p2cp[i])), "p2cp_mm": float(np.mean(p2cp[i]) * to_mm),
-            "med": float(np.mean(euclid[i])), "med_mm": float(np.mean(euclid[i]) * to_mm),
-        }
-        for i, art in enumerate(articulators)
-    })
-    return info
+        acc.add(loss.item(), outputs, targets, lengths, sentences_ids, sentence_frames, phonemes, reference_arrays)
+    return acc.info(dataloader.dataset.dataset_config)

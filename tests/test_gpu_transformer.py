@@ -218,3 +218,22 @@ def test_transformer_training_step_decreases_loss(dev):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.02, losses
+
+
+def test_run_transformer_test_harness(dev, tmp_path):
+    from torch.utils.data import DataLoader
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import SyntheticArtSpeechDataset, pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance
+    from artspeech_amd.phoneme_to_articulation.transformer.evaluation import run_transformer_test
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    arts = ["lower-lip", "pharynx", "soft-palate-midline", "tongue", "upper-lip"]
+    voc = {"<blank>": 0, "<unk>": 1, **{f"p{i}": i + 2 for i in range(8)}}
+    ds = SyntheticArtSpeechDataset(6, voc, arts, n_samples=50, min_len=3, max_len=8, seed=1)
+    loader = DataLoader(ds, batch_size=3, shuffle=False, collate_fn=pad_sequence_transformer_collate_fn)
+    torch.manual_seed(0)
+    model = ArtSpeechTransformer(len(voc), len(arts), embed_dim=32, num_heads=4, num_layers=1, num_feat=100).to(dev)
+    res = run_transformer_test(0, model, loader, EuclideanDistance("none"), str(tmp_path), sorted(arts), device=dev)
+    assert set(res) == {"loss", *arts} and np.isfinite(res["loss"])
+    assert set(res["tongue"]) == {"x_corr", "y_corr", "p2cp", "p2cp_mm", "med", "med_mm"}
+    import os
+    assert sum(f == "tract_variables.csv" for _, _, fs in os.walk(tmp_path) for f in fs) == 6
