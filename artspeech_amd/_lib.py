@@ -71,6 +71,7 @@ PROTOTYPES = {
     "as_p2cp_utterance_mean": (_I32, [_P, _P, _I32, _I32, _I32, _F, _P, _P]),
     "as_tract_variables_fwd": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "as_area_function_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _D, _D, _P, _P, _P]),
+    "as_evenly_spaced_fx": (_I32, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "as_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
     "as_dropout_fwd": (_I32, [_P, _P, _I64, _F, C.c_uint64, _P]),
     "as_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _P]),

@@ -36,3 +36,47 @@ def area_function(internal_wall, external_wall, alpha=np.pi, beta=2.):
     ac = torch.from_numpy(np.stack([internal_wall.T, external_wall.T])[None].astype(np.float64)).cuda()
     dists, fx = area_function_batched(ac, alpha, beta)
     return dists[0].cpu().numpy(), fx[0].cpu().numpy()
+
+
+def evenly_spaced_fx_batched(x, fx, n_samples=200):
+    """x, fx: (frames, Nw) float64 on the GPU with x increasing along dim 1 -> (frames, 2, n_samples) float32
+    (abscissae, resampled values)."""
+    _lib.require_gpu(x, "x")
+    x, fx = x.to(torch.float64).contiguous(), fx.to(torch.float64).contiguous()
+    frames, nw = x.shape
+    out = torch.empty((frames, 2, n_samples), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().as_evenly_spaced_fx(_lib.ptr(x), _lib.ptr(fx), frames, nw, n_samples, _lib.ptr(out), _lib.stream_ptr()),
+               "as_evenly_spaced_fx")
+    return out
+
+
+def evenly_spaced_fx(x, fx, n_samples=200):
+    """Resample the area function at n_samples evenly spaced abscissae (reference area_function.py:145-159: vertical
+    line x = x_s intersected with the polyline (x, fx)).  Returns a (2, n_samples) float32 tensor like the reference."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("artspeech_amd.area_function needs an MI355X device; there is no CPU path")
+    xt = torch.as_tensor(np.asarray(x, dtype=np.float64)).cuda()[None]
+    ft = torch.as_tensor(np.asarray(fx, dtype=np.float64)).cuda()[None]
+    return evenly_spaced_fx_batched(xt, ft, n_samples)[0].cpu()
+
+
+def _rotate(point, ang_rad):
+    rot = np.array([[np.cos(ang_rad), np.sin(ang_rad)], [-np.sin(ang_rad), np.cos(ang_rad)]])
+    return rot @ point
+
+
+def build_semipolar_grid(center, theta_rad, omega_rad, linear_step, polar_step_rad, grid_res=50):
+    """Maeda's semipolar grid (reference area_function.py:31-110): larynx lines (reversed), polar lines (reversed), mouth
+    lines; every line sampled at grid_res points from its inner to its outer end.  Host-side set-up geometry (a few
+    thousand points, built once): plain numpy, float64, returns (n_lines, grid_res, 2)."""
+    center = np.asarray(center, dtype=np.float64)
+    xs = np.arange(0., -0.5, -linear_step)
+    ys = np.arange(0., 0.5, linear_step)
+    angles = np.arange(theta_rad - polar_step_rad, -(np.pi / 2) + omega_rad, -polar_step_rad)
+    mouth = [(_rotate(np.array([x, 0.]), theta_rad) + center, _rotate(np.array([x, -0.4]), theta_rad) + center) for x in xs]
+    larynx = [(_rotate(np.array([0., y]), omega_rad) + center, _rotate(np.array([0.4, y]), omega_rad) + center) for y in ys]
+    polar = [(center.copy(), _rotate(np.array([0., -0.4]), a) + center) for a in angles]
+    lines = []
+    for p_int, p_ext in larynx[::-1] + polar[::-1] + mouth:
+        lines.append(np.stack([np.linspace(p_int[0], p_ext[0], grid_res), np.linspace(p_int[1], p_ext[1], grid_res)], axis=1))
+    return np.array(lines)

@@ -260,6 +260,38 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
     }
 }
 
+// ---------------------------------------------------------------- evenly spaced resampling of fx over x (fp64 in, fp32 out)
+// out[f][0][s] = x_s = x0 + s * (x_last - x0) / (n - 1) (np.linspace), out[f][1][s] = piecewise-linear fx(x_s):
+// the vertical-line / polyline intersection of area_function.py:145-159 for increasing x.  One thread per sample,
+// binary search of the segment.
+__global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ x, const double* __restrict__ fx, long frames,
+                                                       int n_pts, int n_samples, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= frames * n_samples) return;
+    const long f = idx / n_samples;
+    const int s = (int)(idx - f * n_samples);
+    const double* xf = x + f * n_pts;
+    const double* yf = fx + f * n_pts;
+    const double x0 = xf[0], x1 = xf[n_pts - 1];
+    const double step = n_samples > 1 ? __ddiv_rn(__dsub_rn(x1, x0), (double)(n_samples - 1)) : 0.0;
+    const double xq = s == n_samples - 1 && n_samples > 1 ? x1 : __dadd_rn(x0, __dmul_rn((double)s, step));
+    // largest i with xf[i] <= xq (clamped to the last segment)
+    int lo = 0, hi = n_pts - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xf[mid] <= xq) lo = mid; else hi = mid;
+    }
+    double y;
+    if (n_pts == 1 || xf[hi] == xf[lo]) y = yf[lo];
+    else {
+        const double slope = __ddiv_rn(__dsub_rn(yf[hi], yf[lo]), __dsub_rn(xf[hi], xf[lo]));
+        y = __dadd_rn(__dmul_rn(slope, __dsub_rn(xq, xf[lo])), yf[lo]);
+        if (xq >= xf[hi]) y = yf[hi];
+    }
+    out[(f * 2) * n_samples + s] = (float)xq;
+    out[(f * 2 + 1) * n_samples + s] = (float)y;
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -346,5 +378,15 @@ extern "C" int as_area_function_fwd(const double* internal_wall, const double* e
                        (long)frame_stride, (long)pt_stride, (long)xy_stride, (long)frames, n_pts, alpha, beta,
                        beta == 2.0 ? 1 : 0, dists, fx);
     AS_LAUNCH_CHECK("as_area_function_fwd");
+    return 0;
+}
+
+extern "C" int as_evenly_spaced_fx(const double* x, const double* fx, int64_t frames, int32_t n_pts, int32_t n_samples, float* out,
+                                   void* stream) {
+    AS_REQUIRE(x && fx && out && frames > 0 && n_pts > 0 && n_samples > 0, AS_ERR_BAD_ARG, "as_evenly_spaced_fx: bad argument");
+    const long total = (long)frames * n_samples;
+    hipLaunchKernelGGL(resample_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fx, (long)frames, n_pts,
+                       n_samples, out);
+    AS_LAUNCH_CHECK("as_evenly_spaced_fx");
     return 0;
 }

@@ -262,6 +262,12 @@ int as_row_scale(const float* a, const float* row_scale, float* dst, int64_t row
  * The same (p, seed) regenerates the same mask (that is how the backward works). */
 int as_dropout_fwd(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
+/* evenly_spaced_fx (area_function.py:145-159): resample fx over x (both [frames][n_pts], float64, x increasing) at
+ * n_samples evenly spaced abscissae between x[0] and x[-1]; out float32 [frames][2][n_samples] = (abscissae, values),
+ * i.e. the reference's vertical-line / polyline intersections = piecewise-linear interpolation. */
+int as_evenly_spaced_fx(const double* x, const double* fx, int64_t frames, int32_t n_pts, int32_t n_samples, float* out,
+                        void* stream);
+
 /* torch.optim.Adam semantics (L2 weight decay added to the gradient; train_phoneme_to_articulation.py:
  * 177-181) over flat buffers, one launch.  step is the 1-based step count after this update. */
 int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

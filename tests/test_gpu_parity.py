@@ -480,3 +480,24 @@ def test_full_size_properties(dev):
     model.zero_grad()
     masked_euclidean_loss(model(x, lengths), tgt, lengths).backward()
     assert torch.equal(model.flat.grad, gflat)
+
+
+def test_evenly_spaced_fx_and_grid(dev):
+    from artspeech_amd.area_function import build_semipolar_grid, evenly_spaced_fx, evenly_spaced_fx_batched
+    g = load_golden("area_function")
+    a = g["grid_args"]
+    grid = build_semipolar_grid(a[:2], a[2], a[3], a[4], a[5], int(a[6]))      # pinned by the reference fixture
+    assert grid.shape == g["grid"].shape and np.abs(grid - g["grid"]).max() < 1e-13
+    x, fx = g["dists0"], g["fx0"]
+    xfx = evenly_spaced_fx(x, fx, 200)                                          # unpinned by the reference (shapely absent):
+    ref = O.evenly_spaced_fx(x, fx, 200)                                        # vs the oracle's np.interp restatement
+    assert tuple(xfx.shape) == (2, 200) and xfx.dtype == torch.float32
+    assert np.abs(xfx.numpy() - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    assert xfx[1, 0].item() == np.float32(fx[0]) and xfx[1, -1].item() == np.float32(fx[-1])
+    rng = np.random.RandomState(0)
+    xs = np.cumsum(rng.rand(64, 100) + 1e-3, axis=1)
+    fs = rng.rand(64, 100)
+    out = evenly_spaced_fx_batched(torch.from_numpy(xs).to(dev), torch.from_numpy(fs).to(dev), 37).cpu().numpy()
+    for f in (0, 31, 63):
+        r = O.evenly_spaced_fx(xs[f], fs[f], 37)
+        assert np.abs(out[f] - r).max() < 1e-5
