@@ -20,7 +20,8 @@
 //     [V] row table (embedding folded into W_ih) gathered by token id through an LDS copy of the ids.
 // The backward kernel mirrors this with W_hh^T in registers (lane owns a quarter of the 3H gate rows of
 // one hidden unit's column) and emits the pre-activation gradients; weight gradients are time-batched
-// GEMMs over them (artspeech.hip).
+// GEMMs over them (artspeech.hip).  (Tried and dropped: s_setprio(3) for these waves while weight-gradient GEMMs
+// share the CU from the side stream -- no measurable change, the interference is not VALU issue arbitration.)
 #include "as_common.h"
 
 namespace {

@@ -151,12 +151,20 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the visible GPU(s)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm (one rank per GPU over xGMI); ARTSPEECH_DIST_BACKEND=gloo lets several ranks share ONE
+        # GPU to rehearse the multi-rank code path on a single-GPU box (slow collectives, correctness only)
+        backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from artspeech_amd import _lib
     from artspeech_amd.engine import TrainStep
@@ -191,7 +199,10 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    loss = float(step.loss.item())
+    loss_t = step.loss.detach().clone().reshape(1)
+    if world > 1:
+        dist.all_reduce(loss_t)  # shard losses are scaled by the global frame count: their SUM is the batch loss
+    loss = float(loss_t.item())
     assert np.isfinite(loss), "loss is not finite"
 
     ms_per_step = 1e3 * elapsed / args.steps
