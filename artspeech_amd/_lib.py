@@ -86,6 +86,11 @@ PROTOTYPES = {
     "as_add": (_I32, [_P, _P, _P, _I64, _P]),
     "as_row_scale": (_I32, [_P, _P, _P, _I64, _I32, _P]),
     "as_set_overlap": (None, [_I32]),
+    "as_conv3x3_stem": (_I32, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "as_conv3x3_c32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "as_ln_feat_gelu": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "as_gelu": (_I32, [_P, _P, _I64, _P]),
+    "as_gru_unidir_fwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),
     "as_profile_report": (_I32, [C.c_char_p, _I32]),

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
                 float v = acc[i][j][r] + bj;
                 if (g.act == 1) v = fmaxf(v, 0.f);
                 else if (g.act == 2) v = as_sigmoid(v);
+                else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 float* c = C + (long)row * g.ldc + col;
                 if (g.accumulate) v += *c;
                 *c = v;
@@ -319,7 +320,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
                AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of a_i/a_k must be 1 (a_i=%ld a_k=%ld)", (long)g->a_i, (long)g->a_k);
     AS_REQUIRE((g->b_j == 1) != (g->b_k == 1) || (g->b_j == 1 && g->b_k == 1 && (g->N == 1 || g->K == 1)),
                AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of b_j/b_k must be 1 (b_j=%ld b_k=%ld)", (long)g->b_j, (long)g->b_k);
-    AS_REQUIRE(g->act >= 0 && g->act <= 2, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
+    AS_REQUIRE(g->act >= 0 && g->act <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
     const bool a_kc = g->a_k == 1, b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
     GemmK k;

@@ -40,7 +40,7 @@ template <int H, int LPU, bool TRAIN, bool TOK>
 __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
                                                           long tok_stride, const float* __restrict__ w_hh,
                                                           const float* __restrict__ b_hh, const int* __restrict__ lengths,
-                                                          int T, float* __restrict__ y, float* __restrict__ gates) {
+                                                          int T, float* __restrict__ y, float* __restrict__ gates, int nd) {
     constexpr int CW = 4 * LPU;   // floats of the reduction index covered by one ds_read_b128 of every lane of a unit
     constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
     constexpr int NT = LPU * H;   // threads
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
 
     // pad_packed_sequence: outputs of padded frames are exact zeros
     for (long i = (long)len * H + tid; i < (long)T * H; i += NT)
-        y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
+        y[((long)b * T + i / H) * nd * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
         for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
@@ -77,9 +77,10 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     // re-deriving them from t (the address arithmetic otherwise rivals the FMAs in issue slots).
     const int t0 = dir ? len - 1 : 0;
     const int dt = dir ? -1 : 1;
-    float* yb = y + dir * H + j;                     // + frame * 2H
-    float* gb = gates + (long)dir * 4 * H + j;       // + frame * 8H, planes r, z, n, hn at + plane * H   (TRAIN)
-    const float* gib = gi + (long)dir * 3 * H + j;   // + row * 6H
+    float* yb = y + dir * H + j;                     // + frame * nd*H
+    float* gb = gates + (long)dir * 4 * H + j;       // + frame * nd*4H, planes r, z, n, hn at + plane * H   (TRAIN)
+    const float* gib = gi + (long)dir * 3 * H + j;   // + row * nd*3H
+    const long ys = (long)nd * H, gs = (long)nd * 4 * H, is = (long)nd * 3 * H;
     long fr = (long)b * T + t0;                      // frame index of the current step
     // the LPU lanes of a unit hold identical gate values: lane q stores planes q, q + LPU, ... (branch-free selects)
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     float gr, gz, gn;
     {
         const long row = TOK ? (long)tok_s[t0] : fr;
-        const float* p = gib + row * 6 * H;
+        const float* p = gib + row * is;
         gr = p[0]; gz = p[H]; gn = p[2 * H];
     }
     int t = t0;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         // On the last step the look-ahead re-reads the current row (stays inside the sequence).
         const int adv = s + 1 < len ? dt : 0;
         const long rown = TOK ? (long)tok_s[t + adv] : fr + adv;
-        const float* pn = gib + rown * 6 * H;
+        const float* pn = gib + rown * is;
         const float ngr = pn[0], ngz = pn[H], ngn = pn[2 * H];
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
         f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
@@ -131,17 +132,17 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         h = hnew;
         // the lanes of a unit hold identical values: all of them store (same word) -> no divergence
         hbuf[cur ^ 1][j] = hnew;
-        yb[fr * 2 * H] = hnew;
+        yb[fr * ys] = hnew;
         if (TRAIN) {
             if (LPU == 4) {
                 const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
                                (__float_as_int(hn) & m3);
-                gb[fr * 8 * H + q * H] = __int_as_float(gv);
+                gb[fr * gs + q * H] = __int_as_float(gv);
             } else {  // two lanes per unit: lane 0 stores r and n, lane 1 stores z and hn
                 const int ga = (__float_as_int(r) & m0) | (__float_as_int(z) & m1);
                 const int gc = (__float_as_int(n) & m0) | (__float_as_int(hn) & m1);
-                gb[fr * 8 * H + q * H] = __int_as_float(ga);
-                gb[fr * 8 * H + (2 + q) * H] = __int_as_float(gc);
+                gb[fr * gs + q * H] = __int_as_float(ga);
+                gb[fr * gs + (2 + q) * H] = __int_as_float(gc);
             }
         }
         gr = ngr; gz = ngz; gn = ngn;
@@ -275,18 +276,17 @@ constexpr int lpu_of(int) { return 4; }
 
 }  // namespace
 
-extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh,
-                                const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y,
-                                float* gates, void* stream) {
-    AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_gru_bidir_fwd: null pointer");
-    AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_fwd: B=%d T=%d", B, T);
-    AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_gru_bidir_fwd: T=%d > 32768 with a token table", T);
+static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
+                          const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, int nd, void* stream) {
+    AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_gru_fwd: null pointer");
+    AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_fwd: B=%d T=%d", B, T);
+    AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_gru_fwd: T=%d > 32768 with a token table", T);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B, 2);
+    dim3 grid(B, nd);
     const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
 #define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
     hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens,       \
-                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates)
+                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd)
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
     else if (gates) AS_GRU_LAUNCH(HH, true, false);         \
@@ -297,13 +297,24 @@ extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t 
         case 64: AS_GRU_FWD(64) break;
         case 128: AS_GRU_FWD(128) break;
         default:
-            as_set_error("as_gru_bidir_fwd: hidden size %d not in {32, 64, 128}", H);
+            as_set_error("as_gru_fwd: hidden size %d not in {32, 64, 128}", H);
             return AS_ERR_UNSUPPORTED;
     }
 #undef AS_GRU_FWD
 #undef AS_GRU_LAUNCH
-    AS_LAUNCH_CHECK("as_gru_bidir_fwd");
+    AS_LAUNCH_CHECK("as_gru_fwd");
     return 0;
+}
+
+extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh,
+                                const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y,
+                                float* gates, void* stream) {
+    return gru_fwd_launch(gi, tokens, tok_stride, w_hh, b_hh, lengths, B, T, H, y, gates, 2, stream);
+}
+
+extern "C" int as_gru_unidir_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int32_t B,
+                                 int32_t T, int32_t H, float* y, void* stream) {
+    return gru_fwd_launch(gi, nullptr, 0, w_hh, b_hh, lengths, B, T, H, y, nullptr, 1, stream);
 }
 
 extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const float* w_hh,

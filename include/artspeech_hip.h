@@ -130,7 +130,7 @@ int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const 
 /* Strided-batched fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32):
  *   C[g][i][j] (+)= act( sum_k Aop[g][i][k] * Bop[g][j][k] + bias[g][j] )
  * Aop[i][k] = A[i*a_i + k*a_k] and Bop[j][k] = B[j*b_j + k*b_k]; one stride of each pair must be 1.
- * act: 0 none, 1 ReLU, 2 sigmoid.  accumulate != 0 adds to C.  b_kshift/b_kT: if b_kT > 0 the B operand's
+ * act: 0 none, 1 ReLU, 2 sigmoid, 3 exact (erf) GELU.  accumulate != 0 adds to C.  b_kshift/b_kT: if b_kT > 0 the B operand's
  * reduction index k is read at k + b_kshift and is zero unless 0 <= (k % b_kT) + b_kshift < b_kT
  * (the h_{t-1} operand of dW_hh). */
 typedef struct as_gemm {
@@ -267,6 +267,31 @@ int as_dropout_fwd(const float* x, float* y, int64_t n, float p, uint64_t seed, 
  * i.e. the reference's vertical-line / polyline intersections = piecewise-linear interpolation. */
 int as_evenly_spaced_fx(const double* x, const double* fx, int64_t frames, int32_t n_pts, int32_t n_samples, float* out,
                         void* stream);
+
+/* ---- DeepSpeech2-style articulatory scorer, inference (phoneme_recognition/deepspeech2.py:90-195) -------------
+ * Feature maps are channels-last  [B][T][D][32]  (the reference's (B, 32, D, T) permuted (0, 3, 2, 1)).
+ * as_conv3x3_stem : nn.Conv2d(Cin, 32, 3, stride 1, padding 1) (:104) of a planar input whose element (b, ci, d, t)
+ *                   sits at x[b*sb + ci*sc + d*sd + t*st]; w [9][32][Cin] with tap = kd*3 + kt (the torch weight
+ *                   permuted (2, 3, 0, 1)); voicing (NULL or [B][T]) is added to every channel/feature (:175-177).
+ * as_conv3x3_c32  : the 32 -> 32 convolutions of ResidualCNN (:22, 25) as an implicit GEMM on the f32 MFMA;
+ *                   w [9][32][32]; res (NULL or [B][T][D][32]) is the block's skip input (`out += x`, :46). */
+int as_conv3x3_stem(const float* x, int64_t sb, int64_t sc, int64_t sd, int64_t st, const float* w, const float* bias,
+                    const float* voicing, float* y, int32_t B, int32_t T, int32_t D, int32_t Cin, void* stream);
+int as_conv3x3_c32(const float* x, const float* w, const float* bias, const float* res, float* y, int32_t B, int32_t T,
+                   int32_t D, void* stream);
+
+/* ResidualCNN's transpose -> LayerNorm(num_features) -> transpose -> GELU (:30-36, 40-44) on x [rows][D][C]:
+ * y[r][d][c] = gelu(LN over d of x[r][:][c], affine gamma[d], beta[d]); eps 1e-5; x == y allowed. */
+int as_ln_feat_gelu(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t D, int32_t C,
+                    void* stream);
+
+/* y = gelu(x) (exact erf form, F.gelu default; RecurrentBlock :66); x == y allowed. */
+int as_gelu(const float* x, float* y, int64_t n, void* stream);
+
+/* nn.GRU(num_layers=1, bidirectional=False) forward over full-length or ragged rows (RecurrentBlock :54-60, 67), h0 = 0:
+ * gi [B][T][3H] = W_ih x + b_ih, w_hh [3H][H], b_hh [3H], y [B][T][H] (zeros at t >= lengths[b]). */
+int as_gru_unidir_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int32_t B, int32_t T,
+                      int32_t H, float* y, void* stream);
 
 /* torch.optim.Adam semantics (L2 weight decay added to the gradient; train_phoneme_to_articulation.py:
  * 177-181) over flat buffers, one launch.  step is the 1-based step count after this update. */

@@ -315,6 +315,48 @@ def gen_transformer(tmod, dataset):
                 gen_nan=bool(gen.isnan().any()), params=sum(p.numel() for p in model.parameters()))
 
 
+def gen_deepspeech2(ds2):
+    """DeepSpeech2 articulatory scorer (phoneme_recognition/deepspeech2.py:90-195) in eval mode, as test() drives it
+    (phoneme_recognition/__init__.py:213-236): logits, features and the topk(k=1) phoneme indices."""
+    out = {}
+    cases = {
+        # adapter + voicing, two residual / recurrent layers (the thesis scorer's structure, scaled down)
+        "deepspeech2_small": dict(in_channels=2, num_residual_layers=2, num_rnn_layers=2, rnn_hidden_size=64, num_classes=11,
+                                  num_features=23, adapter_out_features=16, B=3, T=9, voicing=True, seed=31),
+        # no adapter, no voicing, odd sizes, one layer of each
+        "deepspeech2_plain": dict(in_channels=2, num_residual_layers=1, num_rnn_layers=1, rnn_hidden_size=32, num_classes=7,
+                                  num_features=12, adapter_out_features=None, B=2, T=5, voicing=False, seed=32),
+    }
+    for name, c in cases.items():
+        torch.manual_seed(c["seed"])
+        model = ds2.DeepSpeech2(c["in_channels"], c["num_residual_layers"], c["num_rnn_layers"], c["rnn_hidden_size"],
+                                num_classes=c["num_classes"], num_features=c["num_features"], dropout=0.1,
+                                adapter_out_features=c["adapter_out_features"])
+        init_abs_sum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))  # seed-for-seed init check
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.uniform_(-0.2, 0.2)
+        model.eval()
+        x = torch.rand(c["B"], c["in_channels"], c["num_features"], c["T"])
+        voicing = (torch.rand(c["B"], c["T"]) > 0.5).float() if c["voicing"] else None
+        with torch.no_grad():
+            logits, features = model(x, voicing, return_features=True)
+            top = torch.topk(logits, k=1, dim=-1).indices
+        arrays = dict(x=x.numpy(), logits=logits.numpy(), features=features.numpy(), top=top.numpy(),
+                      cfg=np.array([c["in_channels"], c["num_residual_layers"], c["num_rnn_layers"], c["rnn_hidden_size"],
+                                    c["num_classes"], c["num_features"], c["adapter_out_features"] or 0], dtype=np.int64))
+        if voicing is not None:
+            arrays["voicing"] = voicing.numpy()
+        arrays.update(sd_to_np("w.", model.state_dict()))
+        save(name, **arrays)
+        srt = logits.sort(dim=-1).values
+        out[name] = dict(logit_sum=float(logits.sum()), params=model.total_parameters, n_keys=len(model.state_dict()), seed=c["seed"],
+                         init_abs_sum=init_abs_sum, min_top2_gap=float((srt[..., -1] - srt[..., -2]).min()))
+    return out
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)  # for `settings`, `helpers`
@@ -363,6 +405,8 @@ def main():
     sys.modules["phoneme_to_articulation.encoder_decoder.models"] = models  # transformer/models.py:6 imports it by this name
     tmod = _load("ref_transformer_models", "phoneme_to_articulation/transformer/models.py")
     checks["transformer_small"] = gen_transformer(tmod, dataset)
+    ds2 = _load("ref_deepspeech2", "phoneme_recognition/deepspeech2.py")  # file-path import: the package __init__ needs funcy/seaborn
+    checks.update(gen_deepspeech2(ds2))
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
     print(json.dumps(checks, indent=1))

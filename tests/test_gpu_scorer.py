@@ -1,0 +1,87 @@
+"""GPU parity of the DeepSpeech2 articulatory scorer (inference) against fixtures produced by the reference itself and
+against the numpy oracle: logits within 1e-4 (fp32), top-1 phoneme indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_wg
+from oracle import deepspeech2_oracle as DO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(cfg, w, dev):
+    from artspeech_amd.phoneme_recognition import DeepSpeech2
+    c = [int(v) for v in cfg]
+    m = DeepSpeech2(c[0], c[1], c[2], c[3], num_classes=c[4], num_features=c[5], adapter_out_features=c[6] or None)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}, strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["deepspeech2_small", "deepspeech2_plain"])
+def test_scorer_matches_reference_fixture(name, dev):
+    from artspeech_amd.phoneme_recognition import top1_phonemes
+    g = load_golden(name)
+    w, _ = split_wg(g)
+    m = _model(g["cfg"], w, dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    v = torch.from_numpy(g["voicing"]).to(dev) if "voicing" in g else None
+    logits, feats = m(x, v, return_features=True)
+    assert logits.shape == g["logits"].shape and feats.shape == g["features"].shape
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4 * max(1.0, np.abs(g["logits"]).max())
+    assert np.abs(feats.cpu().numpy() - g["features"]).max() < 1e-4
+    assert np.array_equal(top1_phonemes(logits).cpu().numpy(), g["top"])  # bit-exact phoneme indices
+    assert torch.equal(m(x, v), logits)                                   # deterministic, and the default return
+
+
+def _random_state(cfg, seed):
+    from artspeech_amd.phoneme_recognition import DeepSpeech2
+    torch.manual_seed(seed)
+    c = cfg
+    m = DeepSpeech2(c[0], c[1], c[2], c[3], num_classes=c[4], num_features=c[5], adapter_out_features=c[6] or None)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.LayerNorm):
+                mod.weight.uniform_(0.7, 1.3)
+                mod.bias.uniform_(-0.2, 0.2)
+    return {k: v.numpy() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("cfg,B,T,voiced", [
+    ((2, 4, 2, 64, 44, 550, 80), 2, 61, True),    # the thesis scorer: 11 articulators x 50 points, adapter to 80 features
+    ((2, 2, 3, 128, 31, 80, 0), 3, 130, False),   # LibriSpeech-style widths (H=128, no adapter); ragged tile edges
+    ((1, 1, 1, 32, 5, 100, 0), 1, 1, False),      # one frame, one plane, D between the two register-resident LN widths
+    ((3, 1, 1, 32, 5, 200, 0), 2, 7, True),       # D beyond the register-resident LN kernel
+])
+def test_scorer_matches_oracle(cfg, B, T, voiced, dev):
+    w = _random_state(cfg, seed=sum(cfg) + T)
+    m = _model(cfg, w, dev)
+    rng = np.random.default_rng(T)
+    x = rng.random((B, cfg[0], cfg[5], T), dtype=np.float32)
+    v = (rng.random((B, T)) > 0.5).astype(np.float32) if voiced else None
+    want, want_f = DO.forward(w, x, v)
+    got, got_f = m(torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev) if voiced else None, return_features=True)
+    got, got_f = got.cpu().numpy().astype(np.float64), got_f.cpu().numpy().astype(np.float64)
+    assert np.abs(got_f - want_f).max() < 1e-4
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+    # top-1 indices are bit-exact wherever the oracle's own decision margin exceeds fp32 noise
+    srt = np.sort(want, -1)
+    decided = (srt[..., -1] - srt[..., -2]) > 1e-4
+    assert decided.mean() > 0.9
+    assert np.array_equal(got.argmax(-1)[decided], want.argmax(-1)[decided])
+
+
+def test_scorer_rejects_training_mode_and_cpu_inputs(dev):
+    w = _random_state((2, 1, 1, 32, 5, 12, 0), 1)
+    m = _model((2, 1, 1, 32, 5, 12, 0), w, dev)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 2, 12, 3))  # CPU tensor: no CPU path
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 12, 3, device=dev))

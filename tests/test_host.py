@@ -208,3 +208,26 @@ def test_data_parallel_matches_full_batch_gloo(tmp_path):
     res = torch.load(out)
     assert abs(res["loss"] - res["full_loss"]) < 1e-9      # shard losses SUM to the full-batch mean
     assert res["err"] < 1e-5                               # summed shard gradients == full-batch gradients
+
+
+@pytest.mark.parametrize("name", ["deepspeech2_small", "deepspeech2_plain"])
+def test_scorer_state_dict_keys_and_seeded_init_match_reference(name):
+    """Same constructor, key names/shapes and (same seed) the same initial weights as the reference DeepSpeech2."""
+    import json
+    from conftest import GOLDEN, load_golden, split_wg
+    from artspeech_amd.phoneme_recognition import DeepSpeech2
+    g = load_golden(name)
+    w, _ = split_wg(g)
+    c = [int(v) for v in g["cfg"]]
+    with open(os.path.join(GOLDEN, "checksums.json")) as f:
+        chk = json.load(f)["cases"][name]
+    torch.manual_seed(chk["seed"])
+    m = DeepSpeech2(c[0], c[1], c[2], c[3], num_classes=c[4], num_features=c[5], dropout=0.1, adapter_out_features=c[6] or None)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(w.keys())
+    assert all(tuple(sd[k].shape) == w[k].shape for k in w)
+    assert m.total_parameters == chk["params"]
+    init = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    assert abs(init - chk["init_abs_sum"]) < 1e-6 * chk["init_abs_sum"]
+    with pytest.raises(RuntimeError):  # inference only, and never on the CPU
+        m(torch.zeros(1, c[0], c[5], 4))

@@ -161,3 +161,14 @@ def test_transformer_oracle_matches_reference_fixture():
     gen = TO.generate(w, cfg, g["tokens"], g["src_kpm"])
     # autoregressive feedback amplifies the fixture's own fp32 rounding frame after frame (fp64 oracle here)
     assert gen.shape == g["gen"].shape and np.abs(gen - g["gen"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("name", ["deepspeech2_small", "deepspeech2_plain"])
+def test_deepspeech2_oracle_matches_reference_fixture(name):
+    from oracle import deepspeech2_oracle as DO
+    g = load_golden(name)
+    w, _ = split_wg(g)
+    logits, features = DO.forward(w, g["x"], g.get("voicing"))
+    assert logits.shape == g["logits"].shape and np.abs(logits - g["logits"]).max() < 5e-6
+    assert np.abs(features - g["features"]).max() < 5e-6
+    assert np.array_equal(logits.argmax(-1)[..., None], g["top"])  # topk(k=1) phoneme indices, bit-exact
