@@ -57,7 +57,8 @@ def _random_state(cfg, seed):
     ((2, 4, 2, 64, 44, 550, 80), 2, 61, True),    # the thesis scorer: 11 articulators x 50 points, adapter to 80 features
     ((2, 2, 3, 128, 31, 80, 0), 3, 130, False),   # LibriSpeech-style widths (H=128, no adapter); ragged tile edges
     ((1, 1, 1, 32, 5, 100, 0), 1, 1, False),      # one frame, one plane, D between the two register-resident LN widths
-    ((3, 1, 1, 32, 5, 200, 0), 2, 7, True),       # D beyond the register-resident LN kernel
+    ((3, 1, 1, 32, 5, 200, 0), 2, 7, True),       # D beyond the register-resident LN kernel and the LDS halo tile
+    ((4, 1, 1, 32, 5, 24, 0), 2, 11, True),       # plane count without a specialised stem kernel
 ])
 def test_scorer_matches_oracle(cfg, B, T, voiced, dev):
     w = _random_state(cfg, seed=sum(cfg) + T)
