@@ -7,6 +7,9 @@
 // so that a lane's MFMA operand (A[i = lane&31][k = lane>>5]) is always one conflict-free ds_read_b32.
 // 256 threads = 4 waves in a 2x2 arrangement; global->register->LDS staging is software pipelined
 // (loads of tile t+1 in flight while the matrix core works on tile t), one barrier per K tile.
+#include <cstdlib>
+#include <cstring>
+
 #include "as_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -146,7 +149,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ s, int i, int k)
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_kernel(GemmK g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     // ONE LDS image per operand: the next tile waits in registers while this one is consumed, so a
     // second LDS buffer would only halve the resident workgroups (34 KB -> 4 per CU, 4 waves per SIMD:
@@ -157,110 +160,168 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int tiles_m = (g.M + BM - 1) / BM;
-    const int tm_idx = blockIdx.x % tiles_m, tn_idx = blockIdx.x / tiles_m;
-    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-    const int bz = blockIdx.z;
-    const float* A = g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch);
-    const float* B = g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch);
-    float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    // persistent workgroups: each walks output tiles (tile, k-split, batch) with the grid as stride.  The next tile's first
+    // operand loads are issued BEFORE this tile's C stores, and the stores are fire-and-forget: they drain under the next
+    // tile's MFMAs instead of holding the workgroup's slot until they land (measured before: 13 us of a 53 us tile at
+    // K = 256, every workgroup of a round storing at the same moment).
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_split = tiles_m * tiles_n;
+    const long per_batch = (long)per_split * g.splitk;
+    const long total = per_batch * g.batch;
+    struct Work {
+        const float* A; const float* B; float* C;
+        int m0, n0, bz, ks, kbeg, kend, tn_idx;
+    };
+    auto decode = [&](long w) {
+        Work x;
+        x.bz = (int)(w / per_batch);
+        const int wrem = (int)(w - x.bz * per_batch);
+        x.ks = wrem / per_split;
+        const int xy = wrem - x.ks * per_split;
+        x.tn_idx = xy / tiles_m;
+        x.m0 = (xy - x.tn_idx * tiles_m) * BM;
+        x.n0 = x.tn_idx * BN;
+        x.A = g.A + (g.a_off ? g.a_off[x.bz] : (long)x.bz * g.a_batch);
+        x.B = g.B + (g.b_off ? g.b_off[x.bz] : (long)x.bz * g.b_batch);
+        x.C = g.C + (g.c_off ? g.c_off[x.bz] : (long)x.bz * g.c_batch);
+        x.kbeg = x.ks * g.kchunk;
+        x.kend = min(g.K, x.kbeg + g.kchunk);
+        return x;
+    };
+    long work = blockIdx.x;
+    if (work >= total) return;
+    Work w = decode(work);
     float4 ra[BM / 32], rb[BN / 32];
-    const int ks = blockIdx.y;
-    const int kbeg = ks * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    const bool do_cs = !A_KC && g.colsum != nullptr && tn_idx == 0 && tid < BM;
-    float cs_acc = 0.f;
-    tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg, g.M, kend, g.a_vec, 0, 0, tid);
-    tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
-    tile_store<BM, A_KC>(sA[0], ra, tid);
-    tile_store<BN, B_KC>(sB[0], rb, tid);
-    __syncthreads();
+    tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
+    tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+    for (;;) {
+        const float* A = w.A;
+        const float* B = w.B;
+        float* C = w.C;
+        const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk = (kend - kbeg + BK - 1) / BK;
+        const bool do_cs = !A_KC && g.colsum != nullptr && w.tn_idx == 0 && tid < BM;
+        float cs_acc = 0.f;
+        __syncthreads();  // the previous tile's fragment reads are done
+        tile_store<BM, A_KC>(sA[0], ra, tid);
+        tile_store<BN, B_KC>(sB[0], rb, tid);
+        __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        constexpr int cur = 0;
-        if (kt + 1 < nk) {
-            tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
-            tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
-        }
-        const float* a_s = sA[cur];
-        const float* b_s = sB[cur];
-        if (do_cs) {  // image [k][BM]: consecutive threads read consecutive words (zero padded beyond M / kend)
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
+                tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+            }
+            const float* a_s = sA[0];
+            const float* b_s = sB[0];
+            if (do_cs) {  // image [k][BM]: consecutive threads read consecutive words (zero padded beyond M / kend)
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) cs_acc += a_s[kk * BM + tid];
-        }
+                for (int kk = 0; kk < BK; ++kk) cs_acc += a_s[kk * BM + tid];
+            }
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
+            for (int kk = 0; kk < BK; kk += 2) {
+                float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = frag<BM, A_KC>(a_s, wm * WM + i * 32 + l31, kk + lh);
+                for (int i = 0; i < TM; ++i) av[i] = frag<BM, A_KC>(a_s, wm * WM + i * 32 + l31, kk + lh);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = frag<BN, B_KC>(b_s, wn * WN + j * 32 + l31, kk + lh);
+                for (int j = 0; j < TN; ++j) bv[j] = frag<BN, B_KC>(b_s, wn * WN + j * 32 + l31, kk + lh);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            __syncthreads();  // every wave is done reading the image
-            tile_store<BM, A_KC>(sA[0], ra, tid);
-            tile_store<BN, B_KC>(sB[0], rb, tid);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (g.splitk > 1) {
-        const int ncs = g.colsum ? 1 : 0;
-        const long W = g.N + ncs;
-        float* slab = g.slab + ((long)ks * g.batch + bz) * (long)g.M * W;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < g.M) slab[(long)row * W + col] = acc[i][j][r];
-                }
-        }
-        if (do_cs && m0 + tid < g.M) slab[(long)(m0 + tid) * W + g.N] = cs_acc;
-        return;
-    }
-    if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
-    const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + l31;
-        if (col >= g.N) continue;
-        const float bj = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bj;
-                if (g.act == 1) v = fmaxf(v, 0.f);
-                else if (g.act == 2) v = as_sigmoid(v);
-                else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                float* c = C + (long)row * g.ldc + col;
-                if (g.accumulate) v += *c;
-                *c = v;
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                __syncthreads();  // every wave is done reading the image
+                tile_store<BM, A_KC>(sA[0], ra, tid);
+                tile_store<BN, B_KC>(sB[0], rb, tid);
+                __syncthreads();
             }
         }
+
+        // the next tile's first operand tiles go in flight ahead of this tile's stores
+        work += gridDim.x;
+        const bool more = work < total;
+        const int ks = w.ks;
+        if (more) {
+            w = decode(work);
+            tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
+            tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+        }
+
+        // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const bool whole = m0 + BM <= g.M;  // workgroup-uniform: whole rows, only a per-lane column predicate
+        if (g.splitk > 1) {
+            const int ncs = g.colsum ? 1 : 0;
+            const long W = g.N + ncs;
+            float* slab = g.slab + ((long)ks * g.batch + bz) * (long)g.M * W;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 32 + l31;
+                if (col >= g.N) continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < g.M) slab[(long)row * W + col] = acc[i][j][r];
+                    }
+            }
+            if (do_cs && m0 + tid < g.M) slab[(long)(m0 + tid) * W + g.N] = cs_acc;
+        } else {
+            if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
+            const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
+            if (whole && !g.accumulate) {
+                float* c0 = C + (long)(m0 + wm * WM + 4 * lh) * g.ldc + n0 + wn * WN + l31;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WN + j * 32 + l31;
+                    if (col < g.N) {  // no loads inside: the stores below are issued back to back under the lane mask
+                        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float v = acc[i][j][r] + bj;
+                                if (g.act == 1) v = fmaxf(v, 0.f);
+                                else if (g.act == 2) v = as_sigmoid(v);
+                                else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                                c0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32] = v;
+                            }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WN + j * 32 + l31;
+                    if (col >= g.N) continue;
+                    const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (row >= g.M) continue;
+                            float v = acc[i][j][r] + bj;
+                            if (g.act == 1) v = fmaxf(v, 0.f);
+                            else if (g.act == 2) v = as_sigmoid(v);
+                            else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                            float* c = C + (long)row * g.ldc + col;
+                            if (g.accumulate) v += *c;
+                            *c = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (!more) break;
     }
 }
 
@@ -286,12 +347,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK g) {
     }
 }
 
+// resident workgroups of one kernel instance on the whole device (queried once per instance)
+template <typename Kern>
+int resident_blocks(Kern kern) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return per_cu * cus;
+}
+
 template <int BM, int BN>
 int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
-    dim3 grid(as_cdiv(k.M, BM) * as_cdiv(k.N, BN), k.splitk, batch), block(256);
+    const long work = (long)as_cdiv(k.M, BM) * as_cdiv(k.N, BN) * k.splitk * batch;
+    dim3 block(256);
     // FAST needs whole float4s: aligned operands and contiguous extents that are multiples of 4
     const bool fast = k.a_vec && k.b_vec && (a_kc ? k.K % 4 == 0 : k.M % 4 == 0) && (b_kc ? k.K % 4 == 0 : k.N % 4 == 0);
-#define AS_GEMM_LAUNCH(AK, BK_, F) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k)
+#define AS_GEMM_LAUNCH(AK, BK_, F)                                                                   \
+    do {                                                                                             \
+        static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, AK, BK_, F>);               \
+        const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);            \
+    } while (0)
     if (fast) {
         if (a_kc && b_kc) AS_GEMM_LAUNCH(true, true, true);
         else if (a_kc && !b_kc) AS_GEMM_LAUNCH(true, false, true);
@@ -343,9 +420,13 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
         k.b_vec = aligned16(g->B) && b_ld % 4 == 0;
     }
     AS_REQUIRE(!(g->colsum && a_kc), AS_ERR_BAD_ARG, "as_gemm_f32: colsum needs an output-contiguous A operand (a_i == 1)");
-    // 128x128 tiles once they fill the chip, else 64x64 for more workgroups
+    // 128x128 tiles once they fill the chip and N fills a tile (N = 100: 60 vs 72 us at 64x64), else 64x64 for more workgroups
     const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
-    if (big >= 256 && g->N >= 96) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
+    static const char* force = getenv("AS_GEMM_TILE");  // tuning aid: "128x128" | "64x128" | "128x64" | "64x64"
+    if (force && !strcmp(force, "128x128")) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
+    if (force && !strcmp(force, "64x128")) return launch<64, 128>(k, g->batch, a_kc, b_kc, st);
+    if (force && !strcmp(force, "128x64")) return launch<128, 64>(k, g->batch, a_kc, b_kc, st);
+    if (!force && big >= 256 && g->N >= 128) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     // few output tiles and a long reduction (weight gradients): split K over workgroups
     const long tiles = (long)as_cdiv(g->M, 64) * as_cdiv(g->N, 64) * g->batch;
     if (g->splitk_ws && !grouped && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {
