@@ -90,6 +90,8 @@ PROTOTYPES = {
     "as_conv3x3_c32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "as_ln_feat_gelu": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "as_gelu": (_I32, [_P, _P, _I64, _P]),
+    "as_lstm_bidir_fwd": (_I32, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "as_lstm_bidir_bwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_gru_unidir_fwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),

@@ -20,6 +20,7 @@ SOURCES = {
     "gemm_f32.hip": [],
     "rowops.hip": [],
     "gru.hip": [],
+    "lstm.hip": [],
     "conv.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
     "artspeech.hip": [],

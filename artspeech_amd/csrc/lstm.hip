@@ -1,0 +1,260 @@
+// Bidirectional LSTM recurrence (nn.LSTM semantics: the RNNType.LSTM switch of phoneme_to_articulation/__init__.py:47-49,
+// used by principal_components/models/rnn.py:58-68) as persistent kernels, same design as gru.hip: one workgroup per
+// (utterance, direction) walks its own sequence (packed-sequence semantics for free), W_hh (4H x H) lives in registers
+// spread over 4 lanes per hidden unit (128 weight VGPRs per lane at H = 128), h_{t-1} in double-buffered LDS with one
+// barrier per step, dot products finished with DPP quad permutes, inputs of the next step loaded one step ahead.
+//   i = s(gi_i + W_hi h + b_hi)  f = s(gi_f + ...)  g = tanh(gi_g + ...)  o = s(gi_o + ...)     (gate row order i, f, g, o)
+//   c' = f c + i g,  h' = o tanh(c')
+// The forward keeps i, f, g, o and c' per frame for the backward; the backward emits the pre-activation gradients (one
+// array: input- and hidden-side pre-activations share them), weight gradients are time-batched GEMMs over them.
+#include "as_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+constexpr int LPU = 4;  // lanes per hidden unit
+
+template <int H, bool TRAIN, bool TOK>
+__global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
+                                                           long tok_stride, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ b_hh, const int* __restrict__ lengths, int T,
+                                                           float* __restrict__ y, float* __restrict__ gates) {
+    constexpr int CW = 4 * LPU, NC = H / CW, NT = LPU * H;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    extern __shared__ int tok_s[];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, j = tid / LPU, q = tid % LPU;
+    const int len = lengths[b];
+
+    f32x2 w[4][NC * 2];
+    {
+        const float* wd = w_hh + (long)dir * 4 * H * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(wd + (long)(g * H + j) * H + CW * c + 4 * q);
+                w[g][2 * c] = f32x2{v.x, v.y};
+                w[g][2 * c + 1] = f32x2{v.z, v.w};
+            }
+    }
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = b_hh[dir * 4 * H + g * H + j];
+
+    for (long i = (long)len * H + tid; i < (long)T * H; i += NT)  // pad_packed_sequence: zeros at padded frames
+        y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
+    if (tid < H) hbuf[0][tid] = 0.f;
+    if (TOK)
+        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
+    __syncthreads();
+    if (len <= 0) return;
+
+    const int t0 = dir ? len - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float* yb = y + dir * H + j;                    // + frame * 2H
+    float* gb = gates + (long)dir * 5 * H + j;      // + frame * 10H, planes i, f, g, o, c' at + plane * H   (TRAIN)
+    const float* gib = gi + (long)dir * 4 * H + j;  // + row * 8H
+    long fr = (long)b * T + t0;
+    const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
+
+    float cst = 0.f;
+    float x[4];
+    {
+        const float* p = gib + (TOK ? (long)tok_s[t0] : fr) * 8 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x[g] = p[g * H];
+    }
+    int t = t0;
+    for (int s = 0; s < len; ++s) {
+        const int cur = s & 1;
+        const int adv = s + 1 < len ? dt : 0;  // look-ahead stays inside the sequence on the last step
+        const float* pn = gib + (TOK ? (long)tok_s[t + adv] : fr + adv) * 8 * H;
+        float xn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xn[g] = pn[g * H];
+        const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
+        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their FMAs
+            float4 hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) hv[u] = hp[LPU * (c0 + u) + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) {
+                    const int c = c0 + u;
+                    const f32x2 lo = {hv[u].x, hv[u].y}, hi = {hv[u].z, hv[u].w};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        a[g] = __builtin_elementwise_fma(w[g][2 * c], lo, a[g]);
+                        a[g] = __builtin_elementwise_fma(w[g][2 * c + 1], hi, a[g]);
+                    }
+                }
+        }
+        const float gi_ = as_sigmoid(x[0] + (quad_sum(a[0].x + a[0].y) + bh[0]));
+        const float gf = as_sigmoid(x[1] + (quad_sum(a[1].x + a[1].y) + bh[1]));
+        const float gg = as_tanh(x[2] + (quad_sum(a[2].x + a[2].y) + bh[2]));
+        const float go = as_sigmoid(x[3] + (quad_sum(a[3].x + a[3].y) + bh[3]));
+        cst = gf * cst + gi_ * gg;
+        const float hnew = go * as_tanh(cst);
+        hbuf[cur ^ 1][j] = hnew;  // the lanes of a unit hold identical values: all store the same word
+        yb[fr * 2 * H] = hnew;
+        if (TRAIN) {
+            const int gv = (__float_as_int(gi_) & m0) | (__float_as_int(gf) & m1) | (__float_as_int(gg) & m2) | (__float_as_int(go) & m3);
+            gb[fr * 10 * H + q * H] = __int_as_float(gv);
+            gb[fr * 10 * H + 4 * H] = cst;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x[g] = xn[g];
+        fr += dt;
+        t += dt;
+        __syncthreads();
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(LPU * H) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
+                                                           const float* __restrict__ w_hh, const int* __restrict__ lengths, int T,
+                                                           float* __restrict__ dg) {
+    constexpr int CW = 4 * LPU, NC = 4 * H / CW, NT = LPU * H;
+    __shared__ __attribute__((aligned(16))) float gbuf[2][4 * H];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, k = tid / LPU, q = tid % LPU;
+    const int len = lengths[b];
+
+    f32x2 wt[NC * 2];  // W_hh^T: rows i = CW*c + 4q + ii of column k
+    {
+        const float* wd = w_hh + (long)dir * 4 * H * H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            wt[2 * c] = f32x2{wd[(long)(CW * c + 4 * q) * H + k], wd[(long)(CW * c + 4 * q + 1) * H + k]};
+            wt[2 * c + 1] = f32x2{wd[(long)(CW * c + 4 * q + 2) * H + k], wd[(long)(CW * c + 4 * q + 3) * H + k]};
+        }
+    }
+    for (long i = (long)len * 4 * H + tid; i < (long)T * 4 * H; i += NT) {  // padded frames feed the time-batched GEMMs as zeros
+        const long t = i / (4 * H), c = i % (4 * H);
+        dg[(((long)b * T + t) * 2 + dir) * 4 * H + c] = 0.f;
+    }
+    if (len <= 0) return;
+
+    const int t0 = dir ? 0 : len - 1;  // opposite to the forward walk
+    const int dt = dir ? 1 : -1;
+    const float* gtb = gates + (long)dir * 5 * H + k;  // + frame * 10H
+    const float* dyb = dy + dir * H + k;               // + frame * 2H
+    float* dgb = dg + (long)dir * 4 * H + k;           // + frame * 8H + plane * H
+    const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
+    struct In { float i, f, g, o, c, cprev, dyv; };
+    // c_{prev} of frame t is the cell state of the frame this walk visits next (t + dt); zero beyond the sequence start
+    auto load = [&](long fr, bool has_prev) {
+        In v;
+        const float* gp = gtb + fr * 10 * H;
+        v.i = gp[0]; v.f = gp[H]; v.g = gp[2 * H]; v.o = gp[3 * H]; v.c = gp[4 * H];
+        const float cp = gtb[(fr + (has_prev ? dt : 0)) * 10 * H + 4 * H];
+        v.cprev = has_prev ? cp : 0.f;
+        v.dyv = dyb[fr * 2 * H];
+        return v;
+    };
+    long fr = (long)b * T + t0;
+    float dh = 0.f, dc = 0.f;
+    In cur_in = load(fr, len > 1);
+    for (int s = 0; s < len; ++s) {
+        const int cur = s & 1;
+        const int adv = s + 1 < len ? dt : 0;
+        const In nxt = load(fr + adv, s + 2 < len);
+        const float dht = dh + cur_in.dyv;
+        const float tc = as_tanh(cur_in.c);
+        const float dct = dc + dht * cur_in.o * (1.f - tc * tc);
+        const float p_o = dht * tc * cur_in.o * (1.f - cur_in.o);
+        const float p_i = dct * cur_in.g * cur_in.i * (1.f - cur_in.i);
+        const float p_f = dct * cur_in.cprev * cur_in.f * (1.f - cur_in.f);
+        const float p_g = dct * cur_in.i * (1.f - cur_in.g * cur_in.g);
+        dc = dct * cur_in.f;
+        const float v = __int_as_float((__float_as_int(p_i) & m0) | (__float_as_int(p_f) & m1) | (__float_as_int(p_g) & m2) |
+                                       (__float_as_int(p_o) & m3));
+        gbuf[cur][q * H + k] = v;
+        dgb[fr * 8 * H + q * H] = v;
+        __syncthreads();
+        const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+        for (int c0 = 0; c0 < NC; c0 += 8) {
+            float4 gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) gv[u] = gq[LPU * (c0 + u) + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NC) {
+                    const int c = c0 + u;
+                    a0 = __builtin_elementwise_fma(wt[2 * c], f32x2{gv[u].x, gv[u].y}, a0);
+                    a1 = __builtin_elementwise_fma(wt[2 * c + 1], f32x2{gv[u].z, gv[u].w}, a1);
+                }
+        }
+        dh = quad_sum((a0.x + a0.y) + (a1.x + a1.y));
+        cur_in = nxt;
+        fr += dt;
+        // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    }
+}
+
+}  // namespace
+
+extern "C" int as_lstm_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
+                                 const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, void* stream) {
+    AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_lstm_bidir_fwd: null pointer");
+    AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_lstm_bidir_fwd: B=%d T=%d", B, T);
+    AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_lstm_bidir_fwd: T=%d > 32768 with a token table", T);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B, 2);
+    const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
+#define AS_LSTM_LAUNCH(HH, TR, TK) \
+    hipLaunchKernelGGL((lstm_fwd_kernel<HH, TR, TK>), grid, dim3(LPU * HH), shm, st, gi, tokens, (long)tok_stride, w_hh, b_hh, lengths, T, y, gates)
+#define AS_LSTM_FWD(HH)                                  \
+    if (gates && tokens) AS_LSTM_LAUNCH(HH, true, true); \
+    else if (gates) AS_LSTM_LAUNCH(HH, true, false);     \
+    else if (tokens) AS_LSTM_LAUNCH(HH, false, true);    \
+    else AS_LSTM_LAUNCH(HH, false, false);
+    switch (H) {
+        case 32: AS_LSTM_FWD(32) break;
+        case 64: AS_LSTM_FWD(64) break;
+        case 128: AS_LSTM_FWD(128) break;
+        default:
+            as_set_error("as_lstm_bidir_fwd: hidden size %d not in {32, 64, 128}", H);
+            return AS_ERR_UNSUPPORTED;
+    }
+#undef AS_LSTM_FWD
+#undef AS_LSTM_LAUNCH
+    AS_LAUNCH_CHECK("as_lstm_bidir_fwd");
+    return 0;
+}
+
+extern "C" int as_lstm_bidir_bwd(const float* dy, const float* gates, const float* w_hh, const int32_t* lengths, int32_t B, int32_t T,
+                                 int32_t H, float* dg, void* stream) {
+    AS_REQUIRE(dy && gates && w_hh && lengths && dg, AS_ERR_BAD_ARG, "as_lstm_bidir_bwd: null pointer");
+    AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_lstm_bidir_bwd: B=%d T=%d", B, T);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B, 2);
+#define AS_LSTM_BWD(HH) hipLaunchKernelGGL((lstm_bwd_kernel<HH>), grid, dim3(LPU * HH), 0, st, dy, gates, w_hh, lengths, T, dg)
+    switch (H) {
+        case 32: AS_LSTM_BWD(32); break;
+        case 64: AS_LSTM_BWD(64); break;
+        case 128: AS_LSTM_BWD(128); break;
+        default:
+            as_set_error("as_lstm_bidir_bwd: hidden size %d not in {32, 64, 128}", H);
+            return AS_ERR_UNSUPPORTED;
+    }
+#undef AS_LSTM_BWD
+    AS_LAUNCH_CHECK("as_lstm_bidir_bwd");
+    return 0;
+}

@@ -34,3 +34,13 @@ def sequences_from_dict(datadir, sequences_dict):
                         if os.path.isdir(os.path.join(datadir, subj, s))]
         sequences.extend([(subj, seq) for seq in use_seqs])
     return sequences
+
+
+def make_indices_dict(num_components):
+    """{articulator: n_components} -> {articulator: [latent indices]}, consecutive ranges in insertion order
+    (reference helpers.py:94-114): {'a': 3, 'b': 2} -> {'a': [0, 1, 2], 'b': [3, 4]}."""
+    indices, start = {}, 0
+    for name, count in num_components.items():
+        indices[name] = list(range(start, start + count))
+        start += count
+    return indices

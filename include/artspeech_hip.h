@@ -127,6 +127,19 @@ int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const 
                      const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* dgi, float* dgh,
                      void* stream);
 
+/* Bidirectional LSTM layer, forward / backward (nn.LSTM semantics; the RNNType.LSTM switch of
+ * phoneme_to_articulation/__init__.py:47-49 used by principal_components/models/rnn.py:58-68).  Packed-sequence
+ * semantics as as_gru_bidir_fwd; gate row order i, f, g, o; h0 = c0 = 0.
+ *   gi    : W_ih x + b_ih, [B*T][2][4H], or (tokens != NULL) a table [V][2][4H] indexed by tokens[b*tok_stride + t]
+ *   w_hh  : [2][4H][H], b_hh : [2][4H];  y : [B][T][2H]
+ *   gates : NULL (inference) or [B][T][2][5][H] receiving i, f, g, o, c for the backward
+ * Backward: dy [B][T][2H] -> dg [B][T][2][4H], the gradient of the gate pre-activations (input- and hidden-side
+ * pre-activations share it; zeros at padded frames); weight gradients are time-batched GEMMs over it. */
+int as_lstm_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
+                      const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, void* stream);
+int as_lstm_bidir_bwd(const float* dy, const float* gates, const float* w_hh, const int32_t* lengths, int32_t B, int32_t T,
+                      int32_t H, float* dg, void* stream);
+
 /* Strided-batched fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32):
  *   C[g][i][j] (+)= act( sum_k Aop[g][i][k] * Bop[g][j][k] + bias[g][j] )
  * Aop[i][k] = A[i*a_i + k*a_k] and Bop[j][k] = B[j*b_j + k*b_k]; one stride of each pair must be 1.

@@ -357,6 +357,42 @@ def gen_deepspeech2(ds2):
     return out
 
 
+def gen_principal_components(pc_rnn):
+    """PrincipalComponentsArtSpeech (principal_components/models/rnn.py:36-109) with both cells of the RNNType switch:
+    forward on ragged batches + every parameter gradient of sum(out * dout)."""
+    out = {}
+    cases = {
+        "pc_lstm_small": dict(rnn="lstm", vocab=13, comps={"tongue": 4, "lower-lip": 3}, embed=16, hidden=32, lengths=[9, 7, 4, 1], seed=41),
+        "pc_gru_small": dict(rnn="gru", vocab=11, comps={"tongue": 5, "pharynx": 2, "upper-lip": 1}, embed=24, hidden=64, lengths=[6, 6, 2], seed=42),
+    }
+    for name, c in cases.items():
+        torch.manual_seed(c["seed"])
+        model = pc_rnn.PrincipalComponentsArtSpeech(c["vocab"], c["comps"], embed_dim=c["embed"], hidden_size=c["hidden"], rnn=c["rnn"])
+        init_abs_sum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))  # seed-for-seed init check
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.uniform_(-0.2, 0.2)
+        B, T = len(c["lengths"]), max(c["lengths"])
+        tokens = torch.randint(1, c["vocab"], (B, T))
+        for i, l in enumerate(c["lengths"]):
+            tokens[i, l:] = 0
+        lengths = torch.tensor(c["lengths"])
+        y = model(tokens, lengths)
+        dout = torch.rand_like(y)
+        (y * dout).sum().backward()
+        arrays = dict(tokens=tokens.numpy(), lengths=lengths.numpy(), out=y.detach().numpy(), dout=dout.numpy(),
+                      cfg=np.array([c["vocab"], c["embed"], c["hidden"], model.latent_size, int(c["rnn"] == "lstm")], dtype=np.int64),
+                      comps=np.array(list(c["comps"].values()), dtype=np.int64))
+        arrays.update(sd_to_np("w.", model.state_dict()))
+        arrays.update({"g." + k: p.grad.numpy() for k, p in model.named_parameters()})
+        save(name, **arrays)
+        out[name] = dict(out_sum=float(y.sum()), params=model.total_parameters, n_keys=len(model.state_dict()), seed=c["seed"],
+                         init_abs_sum=init_abs_sum, comps=c["comps"])
+    return out
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)  # for `settings`, `helpers`
@@ -407,6 +443,11 @@ def main():
     checks["transformer_small"] = gen_transformer(tmod, dataset)
     ds2 = _load("ref_deepspeech2", "phoneme_recognition/deepspeech2.py")  # file-path import: the package __init__ needs funcy/seaborn
     checks.update(gen_deepspeech2(ds2))
+    # the genuine RNNType enum: execute the reference package __init__ under another name (its absent imports are shimmed)
+    _shim("vt_tools.bs_regularization", regularize_Bsplines=None)
+    pkg.RNNType = _load("ref_p2a_init", "phoneme_to_articulation/__init__.py").RNNType
+    pc_rnn = _load("ref_pc_rnn", "phoneme_to_articulation/principal_components/models/rnn.py")
+    checks.update(gen_principal_components(pc_rnn))
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
     print(json.dumps(checks, indent=1))

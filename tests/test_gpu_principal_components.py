@@ -1,0 +1,109 @@
+"""GPU parity of the RNNType switch (LSTM / GRU cells) and the principal-components recurrent model: outputs and every
+parameter gradient against fixtures produced by the reference itself, larger cases against the numpy oracle, and the
+backward at full size against a directional finite difference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_wg
+from oracle import principal_components_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(V, comps, E, H, lstm, w, dev):
+    from artspeech_amd.phoneme_to_articulation.principal_components.models import PrincipalComponentsArtSpeech
+    m = PrincipalComponentsArtSpeech(V, comps, embed_dim=E, hidden_size=H, rnn="lstm" if lstm else "gru")
+    if w is not None:
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}, strict=True)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("name", ["pc_lstm_small", "pc_gru_small"])
+def test_matches_reference_fixture_forward_and_gradients(name, dev):
+    g = load_golden(name)
+    w, grads = split_wg(g)
+    V, E, H, latent, lstm = (int(v) for v in g["cfg"])
+    comps = {f"a{i}": int(c) for i, c in enumerate(g["comps"])}
+    m = _model(V, comps, E, H, lstm, w, dev)
+    tokens = torch.from_numpy(g["tokens"]).to(dev)
+    out = m(tokens, torch.from_numpy(g["lengths"]))
+    assert out.shape == g["out"].shape
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 1e-5
+    (out * torch.from_numpy(g["dout"]).to(dev)).sum().backward()
+    for k, p in m.named_parameters():
+        ref = grads[k]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err < 3e-4 * max(1e-3, np.abs(ref).max()), (k, err, np.abs(ref).max())
+    with torch.no_grad():  # inference path (no saved gates) gives the same numbers
+        assert torch.equal(m(tokens, g["lengths"].tolist()), out.detach())
+
+
+@pytest.mark.parametrize("lstm,H,B,T", [(True, 128, 6, 37), (False, 128, 3, 20), (True, 64, 2, 5)])
+def test_matches_oracle(lstm, H, B, T, dev):
+    torch.manual_seed(H + T)
+    comps = {"tongue": 6, "lower-lip": 4, "pharynx": 2}
+    m = _model(29, comps, 64, H, lstm, None, dev)
+    w = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    lengths = sorted(np.random.default_rng(T).integers(1, T + 1, B).tolist(), reverse=True)
+    lengths[0] = T
+    tokens = torch.randint(1, 29, (B, T))
+    want = PO.forward(w, tokens.numpy(), lengths, lstm)
+    with torch.no_grad():
+        got = m(tokens.to(dev), lengths).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-5
+
+
+def test_raw_lstm_kernels_ragged_and_padded(dev):
+    """as_lstm_bidir_fwd/bwd on their own: zeros at padded frames (outputs and gate gradients), batch independence."""
+    from artspeech_amd import _lib
+    from artspeech_amd.phoneme_to_articulation.rnn_ops import BiRNNLayer
+    torch.manual_seed(3)
+    B, T, I, H = 4, 11, 20, 32
+    lengths = torch.tensor([11, 8, 3, 1], dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, I, device=dev, requires_grad=True)
+    w_ih, w_hh = torch.randn(2, 4 * H, I, device=dev) * 0.2, torch.randn(2, 4 * H, H, device=dev) * 0.2
+    b_ih, b_hh = torch.randn(2, 4 * H, device=dev) * 0.1, torch.randn(2, 4 * H, device=dev) * 0.1
+    y = BiRNNLayer.apply(x, w_ih, w_hh, b_ih, b_hh, lengths, "lstm")
+    for b, l in enumerate(lengths.tolist()):
+        assert torch.all(y[b, l:] == 0)
+    y.sum().backward()
+    for b, l in enumerate(lengths.tolist()):
+        assert torch.all(x.grad[b, l:] == 0)
+    # utterance 1 alone gives the same rows (workgroups are independent)
+    y1 = BiRNNLayer.apply(x[1:2].detach(), w_ih, w_hh, b_ih, b_hh, lengths[1:2].contiguous(), "lstm")
+    assert torch.equal(y1[0], y[1].detach())
+    _ = _lib
+
+
+@pytest.mark.parametrize("lstm", [True, False])
+def test_full_size_backward_matches_finite_difference(lstm, dev):
+    """B=32, T=200, H=128: directional derivative of sum(out * dout) along a random parameter direction."""
+    torch.manual_seed(7)
+    m = _model(45, {"a": 6, "b": 6}, 64, 128, lstm, None, dev)
+    B, T = 32, 200
+    lengths = torch.linspace(200, 60, B).int().tolist()
+    tokens = torch.randint(1, 45, (B, T), device=dev)
+    dout = torch.rand(B, T, m.latent_size, device=dev)
+    loss = (m(tokens, lengths) * dout).sum()
+    loss.backward()
+    params = [p for p in m.parameters()]
+    dirs = [torch.randn_like(p) for p in params]
+    analytic = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(params, dirs))
+    eps = 1e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(sgn * eps * d)
+            vals.append(float((m(tokens, lengths).double() * dout.double()).sum()))
+            for p, d in zip(params, dirs):
+                p.sub_(sgn * eps * d)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 2e-2 * max(1.0, abs(analytic)), (numeric, analytic)

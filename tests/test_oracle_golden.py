@@ -172,3 +172,12 @@ def test_deepspeech2_oracle_matches_reference_fixture(name):
     assert logits.shape == g["logits"].shape and np.abs(logits - g["logits"]).max() < 5e-6
     assert np.abs(features - g["features"]).max() < 5e-6
     assert np.array_equal(logits.argmax(-1)[..., None], g["top"])  # topk(k=1) phoneme indices, bit-exact
+
+
+@pytest.mark.parametrize("name", ["pc_lstm_small", "pc_gru_small"])
+def test_principal_components_oracle_matches_reference_fixture(name):
+    from oracle import principal_components_oracle as PO
+    g = load_golden(name)
+    w, _ = split_wg(g)
+    out = PO.forward(w, g["tokens"], g["lengths"], lstm=bool(g["cfg"][4]))
+    assert out.shape == g["out"].shape and np.abs(out - g["out"]).max() < 2e-6
