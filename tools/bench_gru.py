@@ -49,3 +49,31 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     us = 1e3 * e0.elapsed_time(e1) / iters
     print(f"{os.environ.get('ARTSPEECH_LIB', 'default')[-24:]:24s} gru {name}: {us:8.1f} us/launch  {us / T * 1e3:7.1f} ns/step", flush=True)
 
+
+# ---- LSTM cell (RNNType.LSTM): same shapes, 4 gate planes + cell state
+gi4 = torch.randn(B * T, 2, 4 * H, device=dev)
+w4 = torch.randn(2, 4 * H, H, device=dev) * 0.05
+b4 = torch.randn(2, 4 * H, device=dev) * 0.05
+gates5 = torch.empty(B, T, 2, 5, H, device=dev)
+dg4 = torch.empty(B * T, 2, 4 * H, device=dev)
+
+
+def lfwd():
+    return L.as_lstm_bidir_fwd(_lib.ptr(gi4), None, 0, _lib.ptr(w4), _lib.ptr(b4), _lib.ptr(lengths), B, T, H, _lib.ptr(y), _lib.ptr(gates5), st)
+
+
+def lbwd():
+    return L.as_lstm_bidir_bwd(_lib.ptr(dy), _lib.ptr(gates5), _lib.ptr(w4), _lib.ptr(lengths), B, T, H, _lib.ptr(dg4), st)
+
+
+for name, fn in (("fwd", lfwd), ("bwd", lbwd)):
+    for _ in range(3):
+        _lib.check(fn())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    print(f"{'default':24s} lstm {name}: {us:8.1f} us/launch  {us / T * 1e3:7.1f} ns/step", flush=True)
