@@ -4,6 +4,8 @@
 numpy-out contract for one wall pair; ``area_function_batched`` takes the air-column layout
 (frames, 2 walls, 2, Nw) (phoneme_recognition/datasets.py:152, scripts/shape_to_air_column.py:81)
 and runs one wave per frame."""
+import os
+
 import numpy as np
 import torch
 
@@ -80,3 +82,20 @@ def build_semipolar_grid(center, theta_rad, omega_rad, linear_step, polar_step_r
     for p_int, p_ext in larynx[::-1] + polar[::-1] + mouth:
         lines.append(np.stack([np.linspace(p_int[0], p_ext[0], grid_res), np.linspace(p_int[1], p_ext[1], grid_res)], axis=1))
     return np.array(lines)
+
+
+def save_air_column(filepath, internal_wall, external_wall):
+    """Write one frame's air column in the reference's on-disk layout: ``<frame>.npy`` holding (2 walls, 2 coordinates,
+    Nw points) float64, internal wall first (generate_vocal_tract_shape_v2.py:425-431, scripts/shape_to_air_column.py:77-83).
+    Walls are (Nw, 2) arrays as ``area_function`` takes them."""
+    air_column = np.array([np.asarray(internal_wall).T, np.asarray(external_wall).T])
+    np.save(filepath, air_column)
+    return air_column
+
+
+def load_air_columns(directory, frame_ids, device=None):
+    """Read ``<directory>/<frame>.npy`` air columns (phoneme_recognition/datasets.py:151-156) into one (frames, 2, 2, Nw)
+    float64 tensor -- the input layout of ``area_function_batched``."""
+    stack = np.stack([np.load(os.path.join(directory, f"{frame_id}.npy")) for frame_id in frame_ids]).astype(np.float64)
+    t = torch.from_numpy(stack)
+    return t.to(device) if device is not None else t

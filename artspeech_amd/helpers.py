@@ -44,3 +44,21 @@ def make_indices_dict(num_components):
         indices[name] = list(range(start, start + count))
         start += count
     return indices
+
+
+def npy_to_xarticul(array, filepath=None):
+    """(N, 2) coordinates -> the point list of an Xarticul contour file: one "x y" line per point and the terminating
+    "-1 -1" (reference helpers.py:27-45); written to ``filepath`` when given.  Returns the list of lines."""
+    lines = [f"{x} {y}" for x, y in array]
+    lines.append("-1 -1")  # end-of-contour tag of Xarticul
+    if filepath is not None:
+        with open(filepath, "w") as f:
+            f.write("\n".join(lines))
+    return lines
+
+
+def xarticul_to_npy(filepath):
+    """Xarticul contour file -> (N, 2) float64 array; the last line ("-1 -1") is the end tag (reference helpers.py:48-60)."""
+    with open(filepath, "r") as f:
+        rows = [line.strip().split() for line in f.readlines()][:-1]
+    return np.array([[float(v) for v in row] for row in rows])

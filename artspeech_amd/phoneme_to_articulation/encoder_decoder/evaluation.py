@@ -5,8 +5,8 @@ med_mm``).  All per-utterance metrics are computed on the GPU for the whole batc
 moves everything to the CPU and loops over utterances and frames); only the final means cross to the host.
 When the six tract-variable articulators are available (upper incisor injected from the reference
 contour, :93-109) ``tract_variables.csv`` is written per sentence with the reference's column names
-(phoneme_to_articulation/__init__.py:201-297).  The B-spline regularised contour dumps of ``save_outputs``
-need the external vt_tools package and are outside this path.
+(phoneme_to_articulation/__init__.py:201-297), and the per-frame contour ``.npy`` dumps + ``phonemes.csv`` of ``save_outputs``
+(:121-198; the B-spline regularised variant needs the external vt_tools package and raises).
 """
 import csv
 import os
@@ -16,6 +16,7 @@ import torch
 
 from ... import metrics as root_metrics
 from ...tract_variables import REQUIRED_ARTICULATORS, TV_NAMES, UPPER_INCISOR, tract_variables_batched
+from .. import save_outputs
 from ..metrics import masked_euclidean_loss
 
 
@@ -39,7 +40,7 @@ def _write_tract_variables(save_to, sentences_ids, frame_ids, outputs, targets, 
                     item[f"{tv}_{key}_poc_2_x"], item[f"{tv}_{key}_poc_2_y"] = float(p2[b, t, j, 0]), float(p2[b, t, j, 1])
             rows.append(item)
         with open(os.path.join(sentence_dir, "tract_variables.csv"), "w", newline="") as f:
-            writer = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            writer = csv.DictWriter(f, fieldnames=list(rows[0].keys()), lineterminator="\n")  # DataFrame.to_csv layout
             writer.writeheader()
             writer.writerows(rows)
 
@@ -47,8 +48,9 @@ def _write_tract_variables(save_to, sentences_ids, frame_ids, outputs, targets, 
 class _Accumulator:
     """Per-articulator metric lists + file outputs shared by run_test and run_transformer_test."""
 
-    def __init__(self, articulators, epoch_outputs_dir, device):
+    def __init__(self, articulators, epoch_outputs_dir, device, regularize_out=False):
         self.articulators, self.dir, self.device = list(articulators), epoch_outputs_dir, device
+        self.regularize_out = regularize_out
         n = len(self.articulators)
         self.losses = []
         self.euclid, self.p2cp = [[] for _ in range(n)], [[] for _ in range(n)]
@@ -82,6 +84,7 @@ class _Accumulator:
             tv_articulators = arts
         if all(a in tv_articulators for a in REQUIRED_ARTICULATORS) and outputs.shape[-1] >= 50:
             _write_tract_variables(self.dir, sentences_ids, sentence_frames, outputs, targets, lengths, phonemes, tv_articulators)
+        save_outputs(sentences_ids, sentence_frames, outputs, targets, lengths, phonemes, tv_articulators, self.dir, self.regularize_out)
 
     def info(self, dataset_config):
         to_mm = dataset_config.RES * dataset_config.PIXEL_SPACING
@@ -103,7 +106,7 @@ def run_test(epoch, model, dataloader, criterion, outputs_dir, articulators, dev
     epoch_outputs_dir = os.path.join(outputs_dir, str(epoch))
     os.makedirs(epoch_outputs_dir, exist_ok=True)
     model.eval()
-    acc = _Accumulator(articulators, epoch_outputs_dir, device)
+    acc = _Accumulator(articulators, epoch_outputs_dir, device, regularize_out)
     for sentences_ids, sentences, targets, lengths, phonemes, reference_arrays, sentence_frames, _ in dataloader:
         sentences, targets = sentences.to(device), targets.to(device)
         with torch.no_grad():

@@ -15,7 +15,7 @@ def run_transformer_test(epoch, model, dataloader, criterion, outputs_dir, artic
     epoch_outputs_dir = os.path.join(outputs_dir, str(epoch))
     os.makedirs(epoch_outputs_dir, exist_ok=True)
     model.eval()
-    acc = _Accumulator(articulators, epoch_outputs_dir, device)
+    acc = _Accumulator(articulators, epoch_outputs_dir, device, regularize_out)
     for (sentences_ids, sentences, targets, lengths, phonemes, reference_arrays, sentence_frames, _, src_key_padding_mask, _, _,
          _) in dataloader:
         sentences, targets = sentences.to(device), targets.to(device)

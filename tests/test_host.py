@@ -254,3 +254,49 @@ def test_principal_components_model_keys_and_seeded_init_match_reference(name):
     assert abs(init - chk["init_abs_sum"]) < 1e-6 * chk["init_abs_sum"]
     with pytest.raises(RuntimeError):  # never on the CPU
         m(torch.zeros(2, 3, dtype=torch.long), [3, 2])
+
+
+def test_xarticul_text_round_trip(tmp_path):
+    from artspeech_amd.helpers import npy_to_xarticul, xarticul_to_npy
+    arr = np.array([[0.25, 0.5], [1.0, -2.125], [3.0, 4.0]])
+    path = os.path.join(tmp_path, "contour.txt")
+    lines = npy_to_xarticul(arr, path)
+    assert lines == ["0.25 0.5", "1.0 -2.125", "3.0 4.0", "-1 -1"]  # known answer: str() of the coordinates + end tag
+    with open(path) as f:
+        assert f.read() == "\n".join(lines)
+    assert np.array_equal(xarticul_to_npy(path), arr)
+
+
+def test_save_outputs_writes_reference_layout(tmp_path):
+    """<sentence>/contours/<frame>_<articulator>[_true].npy for valid frames only + phonemes.csv (pandas layout)."""
+    from artspeech_amd.phoneme_to_articulation import save_outputs
+    rng = np.random.default_rng(0)
+    out, tgt = rng.random((2, 3, 2, 2, 5), dtype=np.float32), rng.random((2, 3, 2, 2, 5), dtype=np.float32)
+    save_outputs(["s0", "s1"], [[10, 11, 12], [20, 21]], torch.from_numpy(out), torch.from_numpy(tgt), [3, 2],
+                 [["a", "b", "c"], ["d", "e"]], ["tongue", "lower-lip"], str(tmp_path))
+    names = sorted(["tongue", "lower-lip"])  # channel order = sorted articulator names
+    assert np.array_equal(np.load(os.path.join(tmp_path, "s1", "contours", "21_tongue.npy")), out[1, 1, names.index("tongue")])
+    assert np.array_equal(np.load(os.path.join(tmp_path, "s0", "contours", "12_lower-lip_true.npy")), tgt[0, 2, names.index("lower-lip")])
+    assert not os.path.exists(os.path.join(tmp_path, "s1", "contours", "22_tongue.npy"))  # padded frame: nothing written
+    assert len(os.listdir(os.path.join(tmp_path, "s1", "contours"))) == 2 * 2 * 2
+    with open(os.path.join(tmp_path, "s1", "phonemes.csv")) as f:
+        assert f.read() == "sentence,frame,phoneme\ns1,20,d\ns1,21,e\n"
+    import pandas as pd
+    expect = pd.DataFrame([{"sentence": "s0", "frame": 10 + i, "phoneme": p} for i, p in enumerate("abc")]).to_csv(index=False)
+    with open(os.path.join(tmp_path, "s0", "phonemes.csv")) as f:
+        assert f.read() == expect
+    with pytest.raises(NotImplementedError):
+        save_outputs(["s0"], [[1]], out[:1], tgt[:1], [1], [["a"]], ["tongue", "lower-lip"], str(tmp_path), regularize_out=True)
+
+
+def test_air_column_files_round_trip(tmp_path):
+    """<frame>.npy = (2 walls, 2 coordinates, Nw) with the internal wall first, stacked to (frames, 2, 2, Nw) float64."""
+    from artspeech_amd.area_function import load_air_columns, save_air_column
+    rng = np.random.default_rng(1)
+    walls = [(rng.random((7, 2)), rng.random((7, 2))) for _ in range(3)]
+    for f, (inner, outer) in zip((101, 102, 103), walls):
+        arr = save_air_column(os.path.join(tmp_path, f"{f}.npy"), inner, outer)
+        assert arr.shape == (2, 2, 7)
+    air = load_air_columns(str(tmp_path), [101, 103])
+    assert air.shape == (2, 2, 2, 7) and air.dtype == torch.float64
+    assert np.array_equal(air[1, 0].numpy(), walls[2][0].T) and np.array_equal(air[0, 1].numpy(), walls[0][1].T)
