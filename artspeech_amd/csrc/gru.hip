@@ -22,6 +22,8 @@
 // one hidden unit's column) and emits the pre-activation gradients; weight gradients are time-batched
 // GEMMs over them (artspeech.hip).  (Tried and dropped: s_setprio(3) for these waves while weight-gradient GEMMs
 // share the CU from the side stream -- no measurable change, the interference is not VALU issue arbitration.)
+#include <cstdlib>
+
 #include "as_common.h"
 
 namespace {
@@ -268,6 +270,141 @@ __global__ __launch_bounds__(LPU * H) void gru_bwd_kernel(const float* __restric
     }
 }
 
+// Backward recurrence, second layout: the LDS read of the step's 3H gate gradients is what bounds the layout above (every
+// lane reads 3H/4 floats: 24 ds_read_b128 per lane, 8 waves x 24 x 8 cycles = 1536 LDS cycles per step at H = 128, about
+// the whole measured step).  Here a ROW of 16 lanes owns 4 hidden units: each lane holds W_hh^T for those 4 columns over
+// 1/16 of the gate rows (the same 96 weight VGPRs), reads only 3H/16 gate gradients per step (6 ds_read_b128 at H = 128)
+// and the four partial sums are all-reduced across the row with 4 DPP steps each (quad xor 1, xor 2, half-row mirror,
+// row mirror).  Lane r of a row then plays the old role for unit 4*row + (r & 3), plane r >> 2.
+template <int H>
+__global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ gates, const float* __restrict__ w_hh,
+                                                            const int* __restrict__ lengths, int T, float* __restrict__ dgi,
+                                                            float* __restrict__ dgh) {
+    constexpr int NT = 4 * H;
+    constexpr int VL = 3 * H / 16;            // gate rows per lane
+    constexpr int VW = VL % 4 == 0 ? 4 : 2;   // floats per LDS read
+    constexpr int NCH = VL / VW;              // LDS reads per lane per step
+    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, row = tid >> 4, r = tid & 15;
+    const int k0 = row * 4, k = k0 + (r & 3), pl = r >> 2;
+    const int len = lengths[b];
+
+    // wt[kk][p]: W_hh^T rows i = (c*16 + r)*VW + 2*pp (+1), p = c*VW/2 + pp, of column k0 + kk
+    f32x2 wt[4][VL / 2];
+    {
+        const float* wd = w_hh + (long)dir * 3 * H * H;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pp = 0; pp < VW / 2; ++pp) {
+                const int i = (c * 16 + r) * VW + 2 * pp;
+                const float4 lo = *reinterpret_cast<const float4*>(wd + (long)i * H + k0);
+                const float4 hi = *reinterpret_cast<const float4*>(wd + (long)(i + 1) * H + k0);
+                wt[0][c * (VW / 2) + pp] = f32x2{lo.x, hi.x};
+                wt[1][c * (VW / 2) + pp] = f32x2{lo.y, hi.y};
+                wt[2][c * (VW / 2) + pp] = f32x2{lo.z, hi.z};
+                wt[3][c * (VW / 2) + pp] = f32x2{lo.w, hi.w};
+            }
+    }
+    for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += NT) {  // padded frames feed the time-batched GEMMs as zeros
+        const long t = i / (3 * H), c = i % (3 * H);
+        const long o = (((long)b * T + t) * 2 + dir) * 3 * H + c;
+        dgi[o] = 0.f;
+        dgh[o] = 0.f;
+    }
+    if (len <= 0) return;
+
+    const int t0 = dir ? 0 : len - 1;  // opposite to the forward walk
+    const int dt = dir ? 1 : -1;
+    const float* gtb = gates + (long)dir * 4 * H + k;   // + frame * 8H, planes at +0, +H, +2H, +3H
+    const float* yb = y + dir * H + k;                   // + frame * 2H
+    const float* dyb = dy + dir * H + k;                 // + frame * 2H
+    const int sel = pl < 2 ? pl : 2;                     // planes r, z, n; rows 2 and 3 of the quad store the same n word
+    float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
+    float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
+    const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl >= 2 ? -1 : 0;
+    const int u0 = (r & 3) == 0 ? -1 : 0, u1 = (r & 3) == 1 ? -1 : 0, u2 = (r & 3) == 2 ? -1 : 0, u3 = (r & 3) == 3 ? -1 : 0;
+    struct In { float r, z, n, hn, hprev, dyv; };
+    auto load = [&](long fr, bool has_prev) {
+        In v;
+        const float* gp = gtb + fr * 8 * H;
+        v.r = gp[0]; v.z = gp[H]; v.n = gp[2 * H]; v.hn = gp[3 * H];
+        const float hp = yb[(fr + (has_prev ? dt : 0)) * 2 * H];
+        v.hprev = has_prev ? hp : 0.f;
+        v.dyv = dyb[fr * 2 * H];
+        return v;
+    };
+    auto row_sum = [](float v) {  // all-reduce over the 16 lanes of a DPP row
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+        return v;
+    };
+    long fr = (long)b * T + t0;
+    float dh = 0.f;
+    In cur_in = load(fr, len > 1);
+    for (int s = 0; s < len; ++s) {
+        const int cur = s & 1;
+        const int adv = s + 1 < len ? dt : 0;
+        const In nxt = load(fr + adv, s + 2 < len);
+        const float rg = cur_in.r, z = cur_in.z, n = cur_in.n, hn = cur_in.hn;
+        const float dht = dh + cur_in.dyv;
+        const float dn = dht * (1.f - z);
+        const float dz = dht * (cur_in.hprev - n);
+        const float dnt = dn * (1.f - n * n);
+        const float g_r = dnt * hn * rg * (1.f - rg);
+        const float g_z = dz * z * (1.f - z);
+        const float g_hn = dnt * rg;
+        const int rz = (__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1);
+        const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
+        const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
+        gbuf[cur][sel * H + k] = vh;
+        dgib[fr * 6 * H] = vi;
+        dghb[fr * 6 * H] = vh;
+        __syncthreads();
+        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        if constexpr (VW == 4) {
+            const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
+            float4 gv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) gv[c] = gq[c * 16 + r];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x2 lo = {gv[c].x, gv[c].y}, hi = {gv[c].z, gv[c].w};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[kk] = __builtin_elementwise_fma(wt[kk][2 * c], lo, a[kk]);
+                    a[kk] = __builtin_elementwise_fma(wt[kk][2 * c + 1], hi, a[kk]);
+                }
+            }
+        } else {
+            const float2* gq = reinterpret_cast<const float2*>(gbuf[cur]);
+            float2 gv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) gv[c] = gq[c * 16 + r];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x2 g2 = {gv[c].x, gv[c].y};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_elementwise_fma(wt[kk][c], g2, a[kk]);
+            }
+        }
+        const float s0 = row_sum(a[0].x + a[0].y), s1 = row_sum(a[1].x + a[1].y), s2 = row_sum(a[2].x + a[2].y),
+                    s3 = row_sum(a[3].x + a[3].y);
+        const float acc = __int_as_float((__float_as_int(s0) & u0) | (__float_as_int(s1) & u1) | (__float_as_int(s2) & u2) |
+                                         (__float_as_int(s3) & u3));
+        dh = dht * z + acc;
+        cur_in = nxt;
+        fr += dt;
+        // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    }
+}
+
 // Lanes per hidden unit.  Both layouts are built; measured at H = 128, B = 32, T = 200 (tools/bench_gru.py):
 // LPU = 4 (512 threads, two waves per SIMD): forward 0.55 us/step, backward 0.70; LPU = 2 (256 threads, one
 // wave per SIMD, 252 VGPRs): 0.56 / 0.77 -- the second wave hides the first one's LDS / DPP / transcendental
@@ -324,9 +461,13 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: B=%d T=%d", B, T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
-#define AS_GRU_BWD(HH)                                                                                              \
-    hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
-                       T, dgi, dgh)
+    static const bool unit_layout = getenv("AS_GRU_BWD_UNIT") != nullptr;  // ablation: the 4-lanes-per-unit layout
+#define AS_GRU_BWD(HH)                                                                                                        \
+    if (unit_layout)                                                                                                          \
+        hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
+                           T, dgi, dgh);                                                                                      \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh)
     switch (H) {
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
