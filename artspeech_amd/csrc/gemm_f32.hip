@@ -325,6 +325,153 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
     }
 }
 
+// ---- split-precision variant for forward linears (both operands reduction-contiguous, "NT") -----------------------------
+// Every fp32 operand element is split on the fly into PL bf16 pieces (x = h + m [+ l], each piece the bf16 rounding of what
+// is left) and the product is rebuilt from the significant cross terms on the bf16 matrix core (16x the fp32 MFMA rate)
+// with fp32 accumulation:  PL = 3: hh + hm + mh + hl + lh + mm (6 MFMAs, drops terms below 2^-24 of |a||b|: fp32-grade);
+// PL = 2: hh + hm + mh (3 MFMAs, ~2^-16).  LDS image per piece: [row][40 bf16] (80-byte rows: conflict-free ds_read_b128 of
+// the 8-element k groups a lane of v_mfma_f32_32x32x16_bf16 owns).  Same persistent tile walk and epilogue as the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int PL>
+__device__ __forceinline__ void split_store(__bf16* __restrict__ img, int plane_elems, int off, const float4& v) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 piece[PL];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float rest = x[e];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            const __bf16 q = (__bf16)rest;
+            piece[p][e] = q;
+            rest -= (float)q;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PL; ++p) *reinterpret_cast<bf16x4*>(img + p * plane_elems + off) = piece[p];
+}
+
+template <int BM, int BN, int PL>
+__global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(GemmK g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LDK = BK + 8;  // bf16 elements per image row (80 bytes)
+    __shared__ __attribute__((aligned(16))) __bf16 sA[PL * BM * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[PL * BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_batch = tiles_m * tiles_n;
+    const long total = (long)per_batch * g.batch;
+    const int kq = tid & 7, row0 = tid >> 3;  // staging: this thread's float4 column and first row
+    struct Work { const float* A; const float* B; float* C; int m0, n0, bz; };
+    auto decode = [&](long w) {
+        Work x;
+        x.bz = (int)(w / per_batch);
+        const int xy = (int)(w - (long)x.bz * per_batch);
+        const int tn = xy / tiles_m;
+        x.m0 = (xy - tn * tiles_m) * BM;
+        x.n0 = tn * BN;
+        x.A = g.A + (g.a_off ? g.a_off[x.bz] : (long)x.bz * g.a_batch);
+        x.B = g.B + (g.b_off ? g.b_off[x.bz] : (long)x.bz * g.b_batch);
+        x.C = g.C + (g.c_off ? g.c_off[x.bz] : (long)x.bz * g.c_batch);
+        return x;
+    };
+    long work = blockIdx.x;
+    if (work >= total) return;
+    Work w = decode(work);
+    float4 ra[BM / 32], rb[BN / 32];
+    tile_load<BM, true, true>(ra, w.A, g.a_i, 1, w.m0, 0, g.M, g.K, true, 0, 0, tid);
+    tile_load<BN, true, true>(rb, w.B, g.b_j, 1, w.n0, 0, g.N, g.K, true, 0, 0, tid);
+    const int nk = (g.K + BK - 1) / BK;
+    for (;;) {
+        const float* A = w.A;
+        const float* B = w.B;
+        float* C = w.C;
+        const int m0 = w.m0, n0 = w.n0, bz = w.bz;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();  // every wave is done reading the previous image
+#pragma unroll
+            for (int pp = 0; pp < BM / 32; ++pp) split_store<PL>(sA, BM * LDK, (row0 + 32 * pp) * LDK + kq * 4, ra[pp]);
+#pragma unroll
+            for (int pp = 0; pp < BN / 32; ++pp) split_store<PL>(sB, BN * LDK, (row0 + 32 * pp) * LDK + kq * 4, rb[pp]);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                tile_load<BM, true, true>(ra, A, g.a_i, 1, m0, (kt + 1) * BK, g.M, g.K, true, 0, 0, tid);
+                tile_load<BN, true, true>(rb, B, g.b_j, 1, n0, (kt + 1) * BK, g.N, g.K, true, 0, 0, tid);
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM][PL], bf[TN][PL];
+#pragma unroll
+                for (int p = 0; p < PL; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * BM * LDK + (wm * WM + i * 32 + l31) * LDK + ks * 16 + 8 * lh);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[j][p] = *reinterpret_cast<const bf16x8*>(sB + p * BN * LDK + (wn * WN + j * 32 + l31) * LDK + ks * 16 + 8 * lh);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        if (PL == 3) {  // smallest terms first
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][PL - 1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[j][0], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+        }
+        // the next tile's first operand tiles go in flight ahead of this tile's stores
+        work += gridDim.x;
+        const bool more = work < total;
+        if (more) {
+            w = decode(work);
+            tile_load<BM, true, true>(ra, w.A, g.a_i, 1, w.m0, 0, g.M, g.K, true, 0, 0, tid);
+            tile_load<BN, true, true>(rb, w.B, g.b_j, 1, w.n0, 0, g.N, g.K, true, 0, 0, tid);
+        }
+        const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
+        const bool whole = m0 + BM <= g.M;
+        float* c0 = C + (long)(m0 + wm * WM + 4 * lh) * g.ldc + n0 + wn * WN + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (!whole && m0 + wm * WM + 4 * lh + rr >= g.M) continue;
+                    float v = acc[i][j][r] + bj;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = as_sigmoid(v);
+                    else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    float* c = c0 + (long)rr * g.ldc + j * 32;
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
+        }
+        if (!more) break;
+    }
+}
+
 // C (+)= sum over splits of the slab; the extra slab column (if any) is the fused column sum
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK g) {
     const int ncs = g.colsum ? 1 : 0;
@@ -420,6 +567,20 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
         k.b_vec = aligned16(g->B) && b_ld % 4 == 0;
     }
     AS_REQUIRE(!(g->colsum && a_kc), AS_ERR_BAD_ARG, "as_gemm_f32: colsum needs an output-contiguous A operand (a_i == 1)");
+    // split-precision request (forward linears only): both operands reduction-contiguous and float4-clean, else exact fp32
+    if (g->precision != 0 && a_kc && b_kc && k.a_vec && k.b_vec && g->K % 4 == 0 && !g->colsum) {
+        AS_REQUIRE(g->precision == 1 || g->precision == 2, AS_ERR_BAD_ARG, "as_gemm_f32: precision=%d", g->precision);
+        const long work = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
+        if (g->precision == 2) {
+            static const int slots = resident_blocks(gemm_split_nt_kernel<128, 128, 3>);
+            hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, 3>), dim3((unsigned)(work < slots ? work : slots)), dim3(256), 0, st, k);
+        } else {
+            static const int slots = resident_blocks(gemm_split_nt_kernel<128, 128, 2>);
+            hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, 2>), dim3((unsigned)(work < slots ? work : slots)), dim3(256), 0, st, k);
+        }
+        AS_LAUNCH_CHECK("as_gemm_f32(split)");
+        return 0;
+    }
     // 128x128 tiles once they fill the chip and N fills a tile (N = 100: 60 vs 72 us at 64x64), else 64x64 for more workgroups
     const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
     static const char* force = getenv("AS_GEMM_TILE");  // tuning aid: "128x128" | "64x128" | "128x64" | "64x64"

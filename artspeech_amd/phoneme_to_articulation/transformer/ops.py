@@ -7,6 +7,7 @@ channel ``src[g]`` of a channel-major input ``[C][rows][K]``.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -15,10 +16,21 @@ from ... import _lib
 _TABLES = {}
 _SLAB = {}
 
+# Precision of the forward linears of the modules built on these ops (as_gemm.precision): "f32" = exact fp32 MFMA,
+# "bf16x6" / "bf16x3" = fp32 operands split on the fly into 3 / 2 bf16 pieces on the bf16 MFMA, fp32 accumulation.
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+GEMM_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GEMM_PRECISION", "f32")]
+
+
+def set_gemm_precision(name):
+    global GEMM_PRECISION
+    GEMM_PRECISION = PRECISIONS[name]
+
 
 def _gemm(**kw):
     g = _lib.Gemm()
     g.batch = 1
+    g.precision = GEMM_PRECISION
     for k, v in kw.items():
         setattr(g, k, v.data_ptr() if torch.is_tensor(v) else v)
     _lib.check(_lib.lib().as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")

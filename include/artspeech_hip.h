@@ -163,6 +163,10 @@ typedef struct as_gemm {
        multi-channel transformer decoder, whose 132 attention blocks per layer read/write irregular
        (channel, head) slices. */
     const int64_t* a_off; const int64_t* b_off; const int64_t* c_off; const int64_t* bias_off;
+    /* 0: exact fp32 on the f32 MFMA (default).  1 / 2: forward linears (a_k == b_k == 1, float4-clean operands) may run on
+       the bf16 MFMA with every fp32 element split on the fly into 2 / 3 bf16 pieces and the product rebuilt from 3 / 6
+       cross terms with fp32 accumulation (error ~2^-16 / ~2^-23 of sum |a||b|); other shapes silently stay exact. */
+    int32_t precision;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 

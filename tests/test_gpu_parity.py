@@ -61,7 +61,7 @@ def test_bad_arguments_are_reported(dev):
 
 # ------------------------------------------------------------------------------------------- GEMM
 def run_gemm(dev, A, B, M, N, K, a_i, a_k, b_j, b_k, bias=None, act=0, batch=1, ab=0, bb=0, cb=0, biasb=0, ldc=None,
-             accumulate=0, C0=None, kshift=0, kT=0):
+             accumulate=0, C0=None, kshift=0, kT=0, precision=0):
     from artspeech_amd import _lib
     L = _lib.lib()
     ldc = ldc or N
@@ -72,7 +72,7 @@ def run_gemm(dev, A, B, M, N, K, a_i, a_k, b_j, b_k, bias=None, act=0, batch=1, 
     g.M, g.N, g.K = M, N, K
     g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = a_i, a_k, b_j, b_k, ldc
     g.batch, g.a_batch, g.b_batch, g.c_batch, g.bias_batch = batch, ab, bb, cb, biasb
-    g.act, g.accumulate, g.b_kshift, g.b_kT = act, accumulate, kshift, kT
+    g.act, g.accumulate, g.b_kshift, g.b_kT, g.precision = act, accumulate, kshift, kT, precision
     _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
     torch.cuda.synchronize()
     return Cbuf
@@ -105,6 +105,29 @@ def test_gemm_nn_tn(dev, M, N, K):
     c = run_gemm(dev, T_(a2, dev), T_(b, dev), M, N, K, 1, M, 1, N, accumulate=1, C0=c0)
     assert_close(c.cpu().numpy().reshape(M, N), a2.astype(np.float64).T @ b + c0.cpu().numpy().reshape(M, N), rtol=2e-5,
                  atol=2e-5 * np.sqrt(K), what="tn+acc")
+
+
+@pytest.mark.parametrize("M,N,K", [(500, 200, 264), (128, 128, 32), (1, 5, 4), (6400, 256, 256)])
+def test_gemm_split_precision(dev, M, N, K):
+    """as_gemm.precision: fp32 operands split into bf16 pieces on the bf16 MFMA.  Three pieces (six cross terms) are
+    fp32-grade, two pieces (three terms) ~2^-16; shapes the split kernel does not take (K % 4 != 0) stay exact."""
+    rng = np.random.RandomState(M + N + K)
+    a, b, bias = rng.randn(M, K).astype(np.float32), rng.randn(N, K).astype(np.float32), rng.randn(N).astype(np.float32)
+    ref = np.maximum(a.astype(np.float64) @ b.astype(np.float64).T + bias, 0)
+    scale = (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T).max()
+    for precision, tol in ((2, 5e-7), (1, 8e-6)):
+        c = run_gemm(dev, T_(a, dev), T_(b, dev), M, N, K, K, 1, K, 1, bias=T_(bias, dev), act=1, precision=precision)
+        err = np.abs(c.cpu().numpy().reshape(M, N) - ref).max()
+        assert err <= tol * scale, (precision, err / scale)
+    # accumulate + batched through the split kernel
+    c0 = T_(rng.randn(M * N).astype(np.float32), dev)
+    c = run_gemm(dev, T_(a, dev), T_(b, dev), M, N, K, K, 1, K, 1, accumulate=1, C0=c0, precision=2)
+    want = a.astype(np.float64) @ b.astype(np.float64).T + c0.cpu().numpy().reshape(M, N)
+    assert np.abs(c.cpu().numpy().reshape(M, N) - want).max() <= 5e-7 * scale
+    # a reduction-strided operand keeps the exact kernel whatever the request
+    bt = np.ascontiguousarray(b.T)
+    c = run_gemm(dev, T_(a, dev), T_(bt, dev), M, N, K, K, 1, 1, N, precision=1)
+    assert_close(c.cpu().numpy().reshape(M, N), a.astype(np.float64) @ bt, rtol=2e-5, atol=2e-5 * np.sqrt(K), what="nn exact")
 
 
 def test_gemm_batched_strided_and_shift(dev):
