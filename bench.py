@@ -60,8 +60,8 @@ def phase_bytes(rows):
 
 
 # phase name -> kernel name as rocprofv3 prints it (for the PMC traffic table committed under profiles/)
-PMC_KERNEL = {"gru.bwd_l0": "gru_bwd_kernel<128>", "gru.bwd_l1": "gru_bwd_kernel<128>",
-              "gru.fwd_l0": "gru_fwd_kernel<128, true, true>", "gru.fwd_l1": "gru_fwd_kernel<128, true, false>"}
+PMC_KERNEL = {"gru.bwd_l0": "gru_bwd_row_kernel<128>", "gru.bwd_l1": "gru_bwd_row_kernel<128>",
+              "gru.fwd_l0": "gru_fwd_kernel<128, 4, true, true>", "gru.fwd_l1": "gru_fwd_kernel<128, 4, true, false>"}
 
 
 def pmc_traffic(phase):
