@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import _lib
-from ..encoder_decoder.models import _build_views, _numel
+from ..encoder_decoder.models import _build_views, _numel, _reference_init
 from .ops import Attention, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize
 
 FF_DIM = 2048      # nn.TransformerEncoderLayer's default dim_feedforward (not overridden by the reference, :309-313)
@@ -39,6 +39,55 @@ _BLOCK = (("query.0.weight", "q_w"), ("query.0.bias", "q_b"), ("key.0.weight", "
 def _uniform(shape, fan_in):
     bound = 1.0 / math.sqrt(fan_in)
     return torch.empty(shape).uniform_(-bound, bound)
+
+
+def _reference_order_state(vocab_size, A, d, heads, L, nf):
+    """Default PyTorch initialisation drawn in the reference's construction order (transformer/models.py:291-343), so that
+    the same torch seed yields the same initial weights.  The torch modules built here only consume the generator the way
+    the reference's constructor does and hand over their tensors (reference key -> tensor); nn.TransformerEncoder /
+    nn.TransformerDecoder deep-copy ONE constructed layer, so all layers of a stack start identical (:309-329)."""
+    sd = {}
+
+    def take(prefix, module):
+        for k, v in module.state_dict().items():
+            sd[prefix + k] = v.detach()
+
+    def channel_block(prefix):  # ChannelProcessingLayer.__init__ (:46-69)
+        for name in ("query", "key", "value"):
+            take(f"{prefix}{name}.0.", nn.Linear(d, d))
+        take(prefix + "multihead_attn.", nn.MultiheadAttention(embed_dim=d, num_heads=heads, dropout=0.0, batch_first=True))
+        take(prefix + "layer_norm.", nn.LayerNorm(d))
+
+    take("src_embedding.", nn.Embedding(vocab_size, d))
+    take("tgt_embedding.0.", nn.LayerNorm(nf))
+    take("tgt_embedding.1.", nn.Linear(nf, d))
+    enc = nn.TransformerEncoderLayer(d_model=d, nhead=heads, batch_first=True)
+    for l in range(L):
+        take(f"encoder.layers.{l}.", enc)
+    first = len(sd)
+    pre = "decoder.layers.0."
+    for c in range(A):
+        channel_block(f"{pre}chan_processing_layers.{c}.")
+    for c in range(A):  # ChannelInteractionsLayer.__init__ (:114-131)
+        for j in range(A - 1):
+            channel_block(f"{pre}chan_interaction_layers.{c}.interactions.{j}.")
+        take(f"{pre}chan_interaction_layers.{c}.linear.0.", nn.LayerNorm((A - 1) * d))
+        take(f"{pre}chan_interaction_layers.{c}.linear.1.", nn.Linear((A - 1) * d, d))
+    for c in range(A):
+        channel_block(f"{pre}chan_input_layers.{c}.")
+    take(pre + "feed_forward.0.", nn.LayerNorm(d))
+    take(pre + "feed_forward.1.", nn.Linear(d, d))
+    take(pre + "layer_norm.", nn.LayerNorm(d))
+    layer0 = list(sd.items())[first:]
+    for l in range(1, L):
+        for k, v in layer0:
+            sd[f"decoder.layers.{l}." + k[len(pre):]] = v
+    take("linear.0.", nn.LayerNorm(A * d))
+    take("linear.1.", nn.Linear(A * d, d))
+    for a in range(A):
+        for k, v in _reference_init(None, 1, None, None, nf // 2, False, in_features=d).items():
+            sd[f"predictors.{a}.{k}"] = v
+    return sd
 
 
 class ArtSpeechTransformer(nn.Module):
@@ -56,14 +105,14 @@ class ArtSpeechTransformer(nn.Module):
         self.head_lay = _lib.layout(self.head_dims)
         NB, K10 = A * (A + 1), (A - 1) * d
         P = {}
-        # default PyTorch initialisers by tensor role (not draw-for-draw identical to the reference's construction
-        # order: seed-for-seed initial parity is not provided for this variant)
-        P["src_emb"] = torch.randn(vocab_size, d)
+        # storage only: the values come from _reference_order_state() below (seed-for-seed with the reference)
+        _uniform = lambda shape, fan: torch.empty(shape)  # noqa: E731
+        P["src_emb"] = torch.empty(vocab_size, d)
         P["tgt_ln_w"], P["tgt_ln_b"] = torch.ones(nf), torch.zeros(nf)
         P["tgt_w"], P["tgt_b"] = _uniform((d, nf), nf), _uniform((d,), nf)
         for l in range(L):
             e = f"enc{l}_"
-            P[e + "in_w"], P[e + "in_b"] = nn.init.xavier_uniform_(torch.empty(3 * d, d)), torch.zeros(3 * d)
+            P[e + "in_w"], P[e + "in_b"] = torch.empty(3 * d, d), torch.zeros(3 * d)
             P[e + "o_w"], P[e + "o_b"] = _uniform((d, d), d), torch.zeros(d)
             P[e + "l1_w"], P[e + "l1_b"] = _uniform((FF_DIM, d), d), _uniform((FF_DIM,), d)
             P[e + "l2_w"], P[e + "l2_b"] = _uniform((d, FF_DIM), FF_DIM), _uniform((d,), FF_DIM)
@@ -73,7 +122,7 @@ class ArtSpeechTransformer(nn.Module):
         for name, shape, fan in (("q_w", (NB, d, d), d), ("q_b", (NB, d), d), ("k_w", (NB, d, d), d), ("k_b", (NB, d), d),
                                  ("v_w", (NB, d, d), d), ("v_b", (NB, d), d), ("o_w", (NB, d, d), d)):
             layer0[name] = _uniform(shape, fan)
-        layer0["in_w"] = torch.stack([nn.init.xavier_uniform_(torch.empty(3 * d, d)) for _ in range(NB)])
+        layer0["in_w"] = torch.stack([torch.empty(3 * d, d) for _ in range(NB)])
         layer0["in_b"], layer0["o_b"] = torch.zeros(NB, 3 * d), torch.zeros(NB, d)
         layer0["ln_w"], layer0["ln_b"] = torch.ones(NB, d), torch.zeros(NB, d)
         layer0["il_ln_w"], layer0["il_ln_b"] = torch.ones(A, K10), torch.zeros(A, K10)
@@ -105,6 +154,9 @@ class ArtSpeechTransformer(nn.Module):
         self.register_buffer("pe", pe)  # exposed as "pos_encoding.pe" like the reference's persistent buffer
         self.register_buffer("start", torch.zeros(1, 1, A, nf), persistent=False)
         self._map = self._build_key_map()
+        init = _reference_order_state(vocab_size, A, d, num_heads, L, nf)
+        init["pos_encoding.pe"] = self.pe
+        self.load_state_dict(init)
         self._grad_mode_hint = None
         # block groups of a decoder layer: (slice into the block stacks, tgt channel per block, src channel per block)
         inter_pairs = [(c, i) for c in range(A) for i in range(A) if i != c]

@@ -259,6 +259,7 @@ def gen_transformer(tmod, dataset):
     torch.manual_seed(21)
     V, A, d, heads, L, nf = 13, 3, 32, 4, 2, 20
     model = tmod.ArtSpeechTransformer(V, A, embed_dim=d, num_heads=heads, num_layers=L, num_feat=nf)
+    init_abs_sum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))  # seed-for-seed init check (seed 21)
     # decoder layers start as deep copies (identical weights): perturb them so the fixture tells layers apart
     with torch.no_grad():
         for prm in model.decoder.parameters():
@@ -312,7 +313,8 @@ def gen_transformer(tmod, dataset):
     save("transformer_small", **arrays)
     return dict(out_sum=float(out_nograd.sum()), gen_sum=float(gen.nansum()), n_keys=len(model.state_dict()),
                 enc_pad_zero_nograd=bool((enc_nograd[1, 5:] == 0).all()), enc_pad_zero_grad=bool((enc_grad[1, 5:] == 0).all()),
-                gen_nan=bool(gen.isnan().any()), params=sum(p.numel() for p in model.parameters()))
+                gen_nan=bool(gen.isnan().any()), params=sum(p.numel() for p in model.parameters()), seed=21,
+                init_abs_sum=init_abs_sum)
 
 
 def gen_deepspeech2(ds2):

@@ -300,3 +300,21 @@ def test_air_column_files_round_trip(tmp_path):
     air = load_air_columns(str(tmp_path), [101, 103])
     assert air.shape == (2, 2, 2, 7) and air.dtype == torch.float64
     assert np.array_equal(air[1, 0].numpy(), walls[2][0].T) and np.array_equal(air[0, 1].numpy(), walls[0][1].T)
+
+
+def test_transformer_seeded_init_matches_reference():
+    """Same torch seed => the reference's initial weights (construction-order draws; layers of a stack start identical)."""
+    import json
+    from conftest import GOLDEN
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    g = load_golden("transformer_small")
+    V, A, d, h, L, nf = (int(v) for v in g["cfg"])
+    with open(os.path.join(GOLDEN, "checksums.json")) as f:
+        chk = json.load(f)["cases"]["transformer_small"]
+    torch.manual_seed(chk["seed"])
+    m = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf)
+    sd = m.state_dict()
+    init = float(sum(v.double().abs().sum() for k, v in sd.items() if k != "pos_encoding.pe"))
+    assert abs(init - chk["init_abs_sum"]) < 1e-9 * chk["init_abs_sum"]
+    assert torch.equal(sd["decoder.layers.0.feed_forward.1.weight"], sd["decoder.layers.1.feed_forward.1.weight"])
+    assert torch.equal(sd["encoder.layers.0.linear1.weight"], sd["encoder.layers.1.linear1.weight"])
