@@ -79,7 +79,18 @@ def test_raw_lstm_kernels_ragged_and_padded(dev):
     # utterance 1 alone gives the same rows (workgroups are independent)
     y1 = BiRNNLayer.apply(x[1:2].detach(), w_ih, w_hh, b_ih, b_hh, lengths[1:2].contiguous(), "lstm")
     assert torch.equal(y1[0], y[1].detach())
-    _ = _lib
+    # token-table form of the input projection (embedding folded into W_ih): same rows gathered inside the kernel
+    V = 7
+    table = torch.randn(V, 2, 4 * H, device=dev)
+    tokens = torch.randint(0, V, (B, T), device=dev)
+    y_tab, y_ref = torch.empty(B, T, 2 * H, device=dev), torch.empty(B, T, 2 * H, device=dev)
+    gi = table[tokens].reshape(B * T, 2, 4 * H).contiguous()
+    L = _lib.lib()
+    _lib.check(L.as_lstm_bidir_fwd(_lib.ptr(table), _lib.ptr(tokens), T, _lib.ptr(w_hh), _lib.ptr(b_hh), _lib.ptr(lengths), B, T, H,
+                                   _lib.ptr(y_tab), None, _lib.stream_ptr()), "as_lstm_bidir_fwd")
+    _lib.check(L.as_lstm_bidir_fwd(_lib.ptr(gi), None, 0, _lib.ptr(w_hh), _lib.ptr(b_hh), _lib.ptr(lengths), B, T, H, _lib.ptr(y_ref), None,
+                                   _lib.stream_ptr()), "as_lstm_bidir_fwd")
+    assert torch.equal(y_tab, y_ref)
 
 
 @pytest.mark.parametrize("lstm", [True, False])
