@@ -392,7 +392,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     if (d->simple) {
         AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st));
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
-        AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st));
+        AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
         AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st, slab, G + L.lin_b, 0));
         AS_TRY(gemm_nn(ws + w.dtab0, H, P + L.lin_w, E, G + L.embedding, E, V, E, H, st));
         return 0;
@@ -422,7 +422,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
                        3 * H, H, R, s2, sl2, G + L.b_hh[0] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
     // embedding + layer-0 input projection through the token table
-    AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st));
+    AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
     AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
     AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st));
     if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side stream's work

@@ -13,7 +13,7 @@ int as_fold(const float* W, const float* gamma, const float* beta, const float* 
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
               float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st);
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
-                    hipStream_t st);
+                    hipStream_t st, float* scratch = nullptr, long scratch_floats = 0);
 int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
                    hipStream_t st);
 int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st);

@@ -210,6 +210,51 @@ __global__ __launch_bounds__(256) void token_segsum_kernel(const float* __restri
     if (col < C) out[(long)v * C + col] = (s0 + s1) + (s2 + s3);
 }
 
+// Two-stage form: grid (V, ceil(C/256), ceil(rows/256)) -- every block handles ONE 256-row chunk (one compaction, a handful
+// of row loads) and writes its partial to part[chunk][v][:]; token_segsum_reduce_kernel adds the chunks in order.  Same
+// result order for every launch (bitwise reproducible), ~25x the parallelism of the single-stage kernel at rows = 6400.
+__global__ __launch_bounds__(256) void token_segsum_part_kernel(const float* __restrict__ x, const int64_t* __restrict__ tokens,
+                                                                long tok_stride, int T, long rows, int C, int V,
+                                                                float* __restrict__ part) {
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    const int v = blockIdx.x;
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    const long base = (long)blockIdx.z * 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long m = base + threadIdx.x;
+    bool match = false;
+    if (m < rows) match = tokens[(m / T) * tok_stride + m % T] == v;
+    const unsigned long long bal = __ballot(match);
+    if (lane == 0) wcount[w] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; ++i) off += wcount[i];
+    const int n = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (match) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
+    __syncthreads();
+    if (col >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        s0 += x[(base + list[i]) * C + col];
+        s1 += x[(base + list[i + 1]) * C + col];
+        s2 += x[(base + list[i + 2]) * C + col];
+        s3 += x[(base + list[i + 3]) * C + col];
+    }
+    for (; i < n; ++i) s0 += x[(base + list[i]) * C + col];
+    part[((long)blockIdx.z * V + v) * C + col] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void token_segsum_reduce_kernel(const float* __restrict__ part, long n, int chunks,
+                                                                  float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long)c * n + i];
+    out[i] = s;
+}
+
 // ---- out[m][:] = table[token(m)][:] --------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ tokens,
                                                           long tok_stride, int T, long rows, int C,
@@ -493,8 +538,16 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
     return 0;
 }
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(token_segsum_kernel, dim3(V, as_cdiv(C, 256)), dim3(256), 0, st, x, tokens, tok_stride, T, rows, C, out);
+                    hipStream_t st, float* scratch, long scratch_floats) {
+    const int chunks = as_cdiv(rows, 256);
+    if (scratch && chunks > 1 && chunks <= 65535 && (long)chunks * V * C <= scratch_floats) {
+        hipLaunchKernelGGL(token_segsum_part_kernel, dim3(V, as_cdiv(C, 256), chunks), dim3(256), 0, st, x, tokens, tok_stride, T, rows,
+                           C, V, scratch);
+        hipLaunchKernelGGL(token_segsum_reduce_kernel, dim3(as_cdiv((long)V * C, 256)), dim3(256), 0, st, scratch, (long)V * C, chunks,
+                           out);
+    } else {
+        hipLaunchKernelGGL(token_segsum_kernel, dim3(V, as_cdiv(C, 256)), dim3(256), 0, st, x, tokens, tok_stride, T, rows, C, out);
+    }
     AS_LAUNCH_CHECK("token_segsum");
     return 0;
 }
