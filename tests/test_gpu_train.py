@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import ROOT
+
 pytestmark = pytest.mark.gpu
 
 ARTS = ["lower-lip", "pharynx", "soft-palate-midline", "tongue", "upper-lip"]  # + upper-incisor injected at test time
@@ -137,3 +139,40 @@ def test_gru_dropout_training_mode(dev):
         out_eval = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
     o_eval, _ = O.artspeech_fwd(sd, x, lengths, A)
     assert np.abs(out_eval.cpu().numpy() - o_eval).max() < 1e-5
+
+
+def test_evaluation_entry_points_write_reference_outputs(dev, tmp_path):
+    """test_phoneme_to_articulation*.py: checkpoint -> test split -> test_results.{json,csv} + per-sentence outputs."""
+    import json
+    import sys
+    import yaml
+    sys.path.insert(0, ROOT)
+    import test_phoneme_to_articulation as cli
+    import test_phoneme_to_articulation_transformer as cli_t
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    with open(os.path.join(ROOT, "configs", "test_synthetic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(test_seq_dict={"num_sentences": 6}, batch_size=3, save_to=str(tmp_path / "gru"), synthetic={"min_len": 5, "max_len": 12})
+    torch.manual_seed(0)
+    ckpt = str(tmp_path / "best_model.pt")
+    torch.save(ArtSpeech(45, len(cfg["articulators"])).state_dict(), ckpt)  # reference-keyed checkpoint
+    cfg["state_dict_fpath"] = ckpt
+    res = cli.main(**cfg)
+    with open(tmp_path / "gru" / "test_results.json") as f:
+        assert json.load(f)["loss"] == pytest.approx(res["loss"])
+    with open(tmp_path / "gru" / "test_results.csv") as f:
+        header, row = f.read().strip().split("\n")
+    arts = sorted(cfg["articulators"])
+    assert header.split(",")[:3] == ["exp", "loss", f"p2cp_{arts[0]}"] and len(header.split(",")) == 2 + 4 * len(arts)
+    assert float(row.split(",")[1]) == pytest.approx(res["loss"])
+    sentence_dirs = os.listdir(tmp_path / "gru" / "test_outputs" / "0")
+    assert len(sentence_dirs) == 6
+    first = tmp_path / "gru" / "test_outputs" / "0" / sentence_dirs[0]
+    assert os.path.exists(first / "phonemes.csv") and os.path.exists(first / "tract_variables.csv") and os.listdir(first / "contours")
+
+    with open(os.path.join(ROOT, "configs", "test_transformer_synthetic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(test_seq_dict={"num_sentences": 2}, batch_size=2, save_to=str(tmp_path / "tf"), synthetic={"min_len": 4, "max_len": 6},
+               model_kwargs={"embed_dim": 32, "num_heads": 4, "num_layers": 1, "num_feat": 100})
+    res = cli_t.main(**cfg)
+    assert np.isfinite(res["loss"]) and os.path.exists(tmp_path / "tf" / "test_results.csv")

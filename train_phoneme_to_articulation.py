@@ -113,6 +113,20 @@ def _make_dataset(datadir, database_name, seq_dict, vocabulary, articulators, cl
                             clip_tails=clip_tails)
 
 
+def build_vocabulary(vocab_filepath):
+    """{token: index}: the two default tokens first, then the JSON list (reference :151-156); without a file, 43 synthetic
+    phoneme names (V = 45)."""
+    vocabulary = {token: i for i, token in enumerate([BLANK, UNKNOWN])}
+    if vocab_filepath is not None:
+        with open(vocab_filepath) as f:
+            tokens = json.load(f)
+    else:
+        tokens = [f"ph{i:02d}" for i in range(43)]
+    for i, token in enumerate(tokens, start=len(vocabulary)):
+        vocabulary[token] = i
+    return vocabulary
+
+
 def main(datadir, database_name, num_epochs, batch_size, patience, learning_rate, weight_decay, train_seq_dict,
          valid_seq_dict, test_seq_dict, vocab_filepath, articulators, model_kwargs=None, num_workers=0, clip_tails=True,
          state_dict_filepath=None, checkpoint_filepath=None, seed=0, synthetic=None, results_dir=None):
@@ -128,14 +142,7 @@ def main(datadir, database_name, num_epochs, batch_size, patience, learning_rate
     last_model_path = os.path.join(results_dir, "last_model.pt")
     save_checkpoint_path = os.path.join(results_dir, "checkpoint.pt")
 
-    vocabulary = {token: i for i, token in enumerate([BLANK, UNKNOWN])}
-    if vocab_filepath is not None:
-        with open(vocab_filepath) as f:
-            tokens = json.load(f)
-    else:
-        tokens = [f"ph{i:02d}" for i in range(43)]
-    for i, token in enumerate(tokens, start=len(vocabulary)):
-        vocabulary[token] = i
+    vocabulary = build_vocabulary(vocab_filepath)
 
     model = ArtSpeech(len(vocabulary), len(articulators), **(model_kwargs or {}))
     if state_dict_filepath is not None:

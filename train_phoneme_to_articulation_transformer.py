@@ -35,6 +35,7 @@ from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDi
 from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, masked_euclidean_loss
 from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
 from artspeech_amd.settings import BLANK, DATASET_CONFIG, TRAIN, UNKNOWN, VALID
+from train_phoneme_to_articulation import build_vocabulary
 
 
 def _world():
@@ -108,14 +109,7 @@ def main(datadir, database_name, num_epochs, batch_size, patience, learning_rate
     device = torch.device("cuda", torch.cuda.current_device())
     results_dir = results_dir or RESULTS_DIR
     os.makedirs(results_dir, exist_ok=True)
-    vocabulary = {token: i for i, token in enumerate([BLANK, UNKNOWN])}
-    if vocab_filepath is not None:
-        with open(vocab_filepath) as f:
-            tokens = json.load(f)
-    else:
-        tokens = [f"ph{i:02d}" for i in range(43)]
-    for i, token in enumerate(tokens, start=len(vocabulary)):
-        vocabulary[token] = i
+    vocabulary = build_vocabulary(vocab_filepath)
     if datadir != "synthetic":
         raise NotImplementedError("real-data loading needs the reference's database_collector / vt_shape_gen stack; "
                                   "use `datadir: synthetic`")
