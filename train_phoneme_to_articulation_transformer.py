@@ -11,7 +11,6 @@
 #
 ####################################################################################################
 import argparse
-import json
 import os
 import random
 import shutil
@@ -34,7 +33,7 @@ from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import (
 from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDistance
 from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, masked_euclidean_loss
 from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
-from artspeech_amd.settings import BLANK, DATASET_CONFIG, TRAIN, UNKNOWN, VALID
+from artspeech_amd.settings import DATASET_CONFIG, TRAIN, VALID
 from train_phoneme_to_articulation import build_vocabulary
 
 
