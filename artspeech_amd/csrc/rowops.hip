@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // ---- masked softmax over the last dim of [Z][Tq][Tk], one wave per row ------------------------------
+// NW = ceil(Tk / 64) values per lane (template: no wasted iterations); loads are branch-free (clamped index + select) so
+// they all go in flight together -- a per-element `if (k < Tk)` load makes hipcc wait for each one.
+template <int NW>
 __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s, long rows, int Tq, int Tk, int heads, int B,
                                                            float scale, const float* __restrict__ attn_mask,
                                                            const float* __restrict__ kpm) {
@@ -383,18 +386,19 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     float* sr = s + row * Tk;
     const float* am = attn_mask ? attn_mask + ((long)b * Tq + q) * Tk : nullptr;
     const float* km = kpm ? kpm + (long)b * Tk : nullptr;
-    constexpr int MAXW = 16;  // Tk <= 1024
-    float v[MAXW];
+    float v[NW], ma[NW], mk[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+        const int k = lane + 64 * c;
+        const int kc = k < Tk ? k : Tk - 1;
+        v[c] = sr[kc];
+        ma[c] = am ? am[kc] : 0.f;
+        mk[c] = km ? km[kc] : 0.f;
+    }
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
-        const int k = lane + 64 * c;
-        float x = -INFINITY;
-        if (k < Tk) {
-            x = sr[k] * scale;
-            if (am) x += am[k];
-            if (km) x += km[k];
-        }
+    for (int c = 0; c < NW; ++c) {
+        const float x = lane + 64 * c < Tk ? v[c] * scale + ma[c] + mk[c] : -INFINITY;
         v[c] = x;
         m = fmaxf(m, x);
     }
@@ -402,22 +406,22 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
-        const int k = lane + 64 * c;
-        const float e = k < Tk ? expf(v[c] - m) : 0.f;  // all -inf row: -inf - -inf = NaN, like PyTorch
+    for (int c = 0; c < NW; ++c) {
+        const float e = lane + 64 * c < Tk ? __expf(v[c] - m) : 0.f;  // all -inf row: -inf - -inf = NaN, like PyTorch
         v[c] = e;
         sum += e;
     }
     sum = as_wave_sum(sum);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
+    for (int c = 0; c < NW; ++c) {
         const int k = lane + 64 * c;
         if (k < Tk) sr[k] = v[c] * inv;
     }
 }
 
 // ---- softmax backward over the last dim, in place on dP: dS = P * (dP - sum_k dP*P) * scale --------
+template <int NW>
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows,
                                                                int Tk, float scale) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -425,19 +429,23 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     if (row >= rows) return;
     const float* pr = p + row * Tk;
     float* dr = dp + row * Tk;
-    constexpr int MAXW = 16;
-    float pv[MAXW], dv[MAXW];
+    float pv[NW], dv[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {  // branch-free: clamped index, padded lanes contribute zero below
+        const int k = lane + 64 * c;
+        const int kc = k < Tk ? k : Tk - 1;
+        pv[c] = pr[kc];
+        dv[c] = dr[kc];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
-        const int k = lane + 64 * c;
-        pv[c] = k < Tk ? pr[k] : 0.f;
-        dv[c] = k < Tk ? dr[k] : 0.f;
+    for (int c = 0; c < NW; ++c) {
+        if (lane + 64 * c >= Tk) pv[c] = 0.f;
         s += pv[c] * dv[c];
     }
     s = as_wave_sum(s);
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
+    for (int c = 0; c < NW; ++c) {
         const int k = lane + 64 * c;
         if (k < Tk) dr[k] = pv[c] * (dv[c] - s) * scale;
     }
@@ -594,8 +602,15 @@ extern "C" int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk,
     AS_REQUIRE(scores && Z > 0 && Tq > 0 && Tk > 0 && heads > 0 && B > 0, AS_ERR_BAD_ARG, "as_attn_softmax: bad argument");
     AS_REQUIRE(Tk <= 1024, AS_ERR_UNSUPPORTED, "as_attn_softmax: Tk=%d > 1024", Tk);
     const long rows = (long)Z * Tq;
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, rows, Tq, Tk, heads, B,
-                       scale, attn_mask, key_padding_mask);
+#define AS_SOFTMAX(NW)                                                                                                      \
+    hipLaunchKernelGGL(attn_softmax_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, rows, Tq, Tk, \
+                       heads, B, scale, attn_mask, key_padding_mask)
+    if (Tk <= 64) AS_SOFTMAX(1);
+    else if (Tk <= 128) AS_SOFTMAX(2);
+    else if (Tk <= 256) AS_SOFTMAX(4);
+    else if (Tk <= 512) AS_SOFTMAX(8);
+    else AS_SOFTMAX(16);
+#undef AS_SOFTMAX
     AS_LAUNCH_CHECK("as_attn_softmax");
     return 0;
 }
@@ -605,8 +620,14 @@ extern "C" int as_attn_softmax_bwd(const float* probs, float* dprobs, int64_t Z,
     AS_REQUIRE(probs && dprobs && Z > 0 && Tq > 0 && Tk > 0, AS_ERR_BAD_ARG, "as_attn_softmax_bwd: bad argument");
     AS_REQUIRE(Tk <= 1024, AS_ERR_UNSUPPORTED, "as_attn_softmax_bwd: Tk=%d > 1024", Tk);
     const long rows = (long)Z * Tq;
-    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs, rows, Tk,
-                       scale);
+#define AS_SOFTMAX_BWD(NW) \
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs, rows, Tk, scale)
+    if (Tk <= 64) AS_SOFTMAX_BWD(1);
+    else if (Tk <= 128) AS_SOFTMAX_BWD(2);
+    else if (Tk <= 256) AS_SOFTMAX_BWD(4);
+    else if (Tk <= 512) AS_SOFTMAX_BWD(8);
+    else AS_SOFTMAX_BWD(16);
+#undef AS_SOFTMAX_BWD
     AS_LAUNCH_CHECK("as_attn_softmax_bwd");
     return 0;
 }
