@@ -326,6 +326,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
 }
 
 // ---- LayerNorm with optional residual input and grouped affine ------------------------------------
+// one wave per row, NW = ceil(D / 64) values per lane (template: rows are 20 .. 2816 wide in the models); branch-free
+// clamped loads so that all of a lane's loads are in flight together.
+template <int NW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ xhat,
@@ -336,35 +339,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (row >= rows) return;
     const float* xr = x + row * D;
     const float* rr = res ? res + row * D : nullptr;
-    // rows up to 64 * 32 = 2048 wide (the transformer's LayerNorm(10 * d) and LayerNorm(A * d))
-    constexpr int MAXW = 44;
-    float v[MAXW];
+    // group_rows > 0: consecutive blocks of rows share a parameter set; < 0: parameter set = row % (-group_rows)
+    const long g = group_rows > 0 ? row / group_rows : (group_rows < 0 ? row % (-group_rows) : 0);
+    float v[NW], ga[NW], be[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+        const int i = lane + 64 * c;
+        const int ic = i < D ? i : D - 1;
+        v[c] = rr ? xr[ic] + rr[ic] : xr[ic];
+        ga[c] = gamma ? gamma[g * D + ic] : 1.f;
+        be[c] = gamma ? beta[g * D + ic] : 0.f;
+    }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
-        const int i = lane + 64 * c;
-        v[c] = i < D ? (rr ? xr[i] + rr[i] : xr[i]) : 0.f;
+    for (int c = 0; c < NW; ++c) {
+        if (lane + 64 * c >= D) v[c] = 0.f;
         s += v[c];
     }
     const float mean = as_wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
-        const int i = lane + 64 * c;
-        const float d = i < D ? v[c] - mean : 0.f;
+    for (int c = 0; c < NW; ++c) {
+        const float d = lane + 64 * c < D ? v[c] - mean : 0.f;
         v[c] = d;
         q += d * d;
     }
     const float rs = 1.0f / sqrtf(as_wave_sum(q) / D + eps);
-    // group_rows > 0: consecutive blocks of rows share a parameter set; < 0: parameter set = row % (-group_rows)
-    const long g = group_rows > 0 ? row / group_rows : (group_rows < 0 ? row % (-group_rows) : 0);
 #pragma unroll
-    for (int c = 0; c < MAXW; ++c) {
+    for (int c = 0; c < NW; ++c) {
         const int i = lane + 64 * c;
         if (i < D) {
             const float xh = v[c] * rs;
             if (xhat) xhat[row * D + i] = xh;
-            if (y) y[row * D + i] = gamma ? xh * gamma[g * D + i] + beta[g * D + i] : xh;
+            if (y) y[row * D + i] = xh * ga[c] + be[c];
         }
     }
     if (rstd && lane == 0) rstd[row] = rs;
@@ -585,8 +592,16 @@ extern "C" int as_layernorm_fwd(const float* x, const float* res, const float* g
                                 float* rstd, int64_t rows, int32_t D, int64_t group_rows, void* stream) {
     AS_REQUIRE(x && (y || xhat) && rows > 0 && D > 0 && (!gamma == !beta), AS_ERR_BAD_ARG, "as_layernorm_fwd: bad argument");
     AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd: row length %d > %d", D, 64 * 44);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, xhat,
-                       rstd, (long)rows, D, (long)group_rows, 1e-5f);
+#define AS_LN_FWD(NW)                                                                                                          \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, \
+                       xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f)
+    if (D <= 64) AS_LN_FWD(1);
+    else if (D <= 128) AS_LN_FWD(2);
+    else if (D <= 256) AS_LN_FWD(4);
+    else if (D <= 512) AS_LN_FWD(8);
+    else if (D <= 1024) AS_LN_FWD(16);
+    else AS_LN_FWD(44);
+#undef AS_LN_FWD
     AS_LAUNCH_CHECK("as_layernorm_fwd");
     return 0;
 }
