@@ -18,6 +18,7 @@ building blocks are autograd Functions whose forward and backward both run on th
 wires them.  Parameters are stored stacked over blocks (one tensor per field and layer).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -88,6 +89,9 @@ def _reference_order_state(vocab_size, A, d, heads, L, nf):
         for k, v in _reference_init(None, 1, None, None, nf // 2, False, in_features=d).items():
             sd[f"predictors.{a}.{k}"] = v
     return sd
+
+
+LAST_ONLY = os.environ.get("ARTSPEECH_GENERATE_FULL_LAST") is None  # ablation switch for generate()'s last-layer restriction
 
 
 class ArtSpeechTransformer(nn.Module):
@@ -278,7 +282,24 @@ class ArtSpeechTransformer(nn.Module):
         return x
 
     # ------------------------------------------------------------------ decoder
-    def _blocks(self, l, group, xhat_tgt, xhat_src, attn_mask, kpm, B):
+    def _memory_kv(self, l, mem_hat):
+        """Source side of the cross-attention blocks of layer l (k / v pre-projections + MHA in-projections of the memory,
+        :47-60 and the in_proj of :62-67): depends on the encoder output only, so generate() computes it once per layer
+        instead of once per generated frame."""
+        P, d = self.P, self.embed_dim
+        sl, _, src_idx = self._groups["input"]
+        n = f"dec{l}_"
+        ident = tuple(range(sl.stop - sl.start))
+        ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
+        wk, bk = FoldLN.apply(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
+        wv, bv = FoldLN.apply(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
+        k = GroupedLinear.apply(mem_hat, wk, bk, src_idx, True)
+        v = GroupedLinear.apply(mem_hat, wv, bv, src_idx, True)
+        in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
+        return (GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False),
+                GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False))
+
+    def _blocks(self, l, group, xhat_tgt, xhat_src, attn_mask, kpm, B, kv=None):
         """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> [G, R, d]."""
         P, d = self.P, self.embed_dim
         sl, tgt_idx, src_idx = self._groups[group]
@@ -287,39 +308,50 @@ class ArtSpeechTransformer(nn.Module):
         ident = tuple(range(G))
         ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
         wq, bq = FoldLN.apply(P[n + "q_w"][sl], ln_w, ln_b, P[n + "q_b"][sl])
-        wk, bk = FoldLN.apply(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
-        wv, bv = FoldLN.apply(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
         q = GroupedLinear.apply(xhat_tgt, wq, bq, tgt_idx, True)
-        k = GroupedLinear.apply(xhat_src, wk, bk, src_idx, True)
-        v = GroupedLinear.apply(xhat_src, wv, bv, src_idx, True)
         in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
         q2 = GroupedLinear.apply(q, in_w[:, :d], in_b[:, :d], ident, False)
-        k2 = GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False)
-        v2 = GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False)
+        if kv is not None:
+            k2, v2 = kv
+        else:
+            wk, bk = FoldLN.apply(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
+            wv, bv = FoldLN.apply(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
+            k = GroupedLinear.apply(xhat_src, wk, bk, src_idx, True)
+            v = GroupedLinear.apply(xhat_src, wv, bv, src_idx, True)
+            k2 = GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False)
+            v2 = GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False)
         ctx = Attention.apply(q2, k2, v2, attn_mask, kpm, B, self.num_heads)
         o = GroupedLinear.apply(ctx, P[n + "o_w"][sl], P[n + "o_b"][sl], ident, False)
         return q + o  # the residual is the PROJECTED query (:98)
 
-    def _decoder_layer(self, l, x, mem_hat, tgt_mask, memory_mask, tgt_kpm, mem_kpm, B):
-        """MultiChannelTransformerDecoderLayer.forward (:216-277) on channel-major x [A, R, d]."""
+    def _decoder_layer(self, l, x, mem_hat, tgt_mask, memory_mask, tgt_kpm, mem_kpm, B, mem_kv=None, last_only=False):
+        """MultiChannelTransformerDecoderLayer.forward (:216-277) on channel-major x [A, R, d].  last_only (generate()'s last
+        layer): only the newest frame's output is consumed, so every query side is restricted to that frame; the self blocks
+        and the key / value side of the interaction blocks still see the whole prefix.  Returns [A, B, d] then."""
         P, A, d = self.P, self.num_articulators, self.embed_dim
         R = x.shape[1]
         n = f"dec{l}_"
         xhat = Normalize.apply(x)
         proc = self._blocks(l, "proc", xhat, xhat, tgt_mask, tgt_kpm, B)                    # [A, R, d]
         phat = Normalize.apply(proc)
-        inter_blocks = self._blocks(l, "inter", phat, phat, tgt_mask, tgt_kpm, B)            # [A*(A-1), R, d]
+        if last_only:
+            assert tgt_mask is None and tgt_kpm is None
+            phat_q = phat.view(A, B, R // B, d)[:, :, -1].contiguous()                        # [A, B, d]: one query row per utterance
+            R = B
+        else:
+            phat_q = phat
+        inter_blocks = self._blocks(l, "inter", phat_q, phat, tgt_mask, tgt_kpm, B)          # [A*(A-1), R, d]
         cat = inter_blocks.view(A, A - 1, R, d).permute(0, 2, 1, 3).reshape(A, R, (A - 1) * d)  # concat over the other channels
         wl, bl = FoldLN.apply(P[n + "il_w"], P[n + "il_ln_w"], P[n + "il_ln_b"], P[n + "il_b"])
         inter = GroupedLinear.apply(Normalize.apply(cat), wl, bl, tuple(range(A)), True)      # [A, R, d]
-        inp = self._blocks(l, "input", Normalize.apply(inter), mem_hat, memory_mask, mem_kpm, B)
+        inp = self._blocks(l, "input", Normalize.apply(inter), mem_hat, memory_mask, mem_kpm, B, kv=mem_kv)
         y = LayerNormAffine.apply(inp, None, P[n + "ln2_w"], P[n + "ln2_b"])
         wf, bf = FoldLN.apply(P[n + "ff_w"][None], P[n + "ff_ln_w"][None], P[n + "ff_ln_b"][None], P[n + "ff_b"][None])
         ff = GroupedLinear.apply(Normalize.apply(y).view(1, A * R, d), wf, bf, (0,), True).view(A, R, d)
         return y + ff
 
     def _generate_one_step(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
-                           memory_key_padding_mask=None):
+                           memory_key_padding_mask=None, memory_kv=None, last_only=False):
         """(bs, seq_len, num_channels, num_feat) -> (bs, seq_len, num_channels, 2, num_feat / 2)  (reference :430-474)."""
         P, A, d, nf = self.P, self.num_articulators, self.embed_dim, self.num_feat
         B, T = tgt.shape[:2]
@@ -330,9 +362,13 @@ class ArtSpeechTransformer(nn.Module):
         emb = GroupedLinear.apply(that[None], w, b, (0,), True).view(B, T, A, d)
         x = F.dropout(emb + self.pe[0, :T].view(1, T, 1, d), self.dropout, train)            # positional encoding per channel
         x = x.permute(2, 0, 1, 3).reshape(A, R, d)                                             # channel-major
-        mem_hat = Normalize.apply(memory)[None]                                                # shared by every cross block
+        mem_hat = Normalize.apply(memory)[None] if memory_kv is None else None                 # shared by every cross block
         for l in range(self.num_layers):
-            x = self._decoder_layer(l, x, mem_hat, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, B)
+            x = self._decoder_layer(l, x, mem_hat, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, B,
+                                    mem_kv=None if memory_kv is None else memory_kv[l],
+                                    last_only=last_only and l == self.num_layers - 1)
+        if last_only:  # x is [A, B, d]: the newest frame only
+            T, R = 1, B
         feat = F.dropout(x.permute(1, 0, 2).reshape(R, A * d), self.dropout, train)
         w, b = FoldLN.apply(P["fin_w"][None], P["fin_ln_w"][None], P["fin_ln_b"][None], P["fin_b"][None])
         feat = GroupedLinear.apply(Normalize.apply(feat)[None], w, b, (0,), True)[0]
@@ -374,7 +410,10 @@ class ArtSpeechTransformer(nn.Module):
             kpm = src_key_padding_mask.contiguous().float()
             memory = self._encode(src.long(), kpm, self._zero_padded())
             tgt = self.start.repeat(B, 1, 1, 1)
+            # the only step-invariant part of the (unmasked, hence non-causal) re-decoding: the memory side of the cross blocks
+            mem_hat = Normalize.apply(memory)[None]
+            memory_kv = [self._memory_kv(l, mem_hat) for l in range(self.num_layers)]
             for _ in range(T):
-                nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm)
+                nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm, memory_kv=memory_kv, last_only=LAST_ONLY)
                 tgt = torch.cat([tgt, nxt[:, -1:].reshape(B, 1, self.num_articulators, self.num_feat)], dim=1)
             return tgt.reshape(B, T + 1, self.num_articulators, 2, self.num_feat // 2)[:, 1:]
