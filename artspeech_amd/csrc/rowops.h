@@ -5,9 +5,6 @@
 int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st);
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
                      int D, hipStream_t st);
-int as_colsum_splits(long rows);
-// partial: as_colsum_splits(rows) * C floats
-int as_colsum(const float* x, long rows, int C, long ldx, float* out, float* partial, hipStream_t st);
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
             int K, hipStream_t st);
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,

@@ -81,30 +81,6 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
     }
 }
 
-// ---- deterministic column sums: stage 1 partial[rs][C], stage 2 out[C] ---------------------------
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, long rows, int C, long ldx,
-                                                     float* __restrict__ partial, int rows_per_split) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const long r0 = (long)blockIdx.y * rows_per_split;
-    long r1 = r0 + rows_per_split;
-    if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    if (col < C)
-        for (long r = r0 + w; r < r1; r += 4) s += x[r * ldx + col];
-    red[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && col < C) partial[(long)blockIdx.y * C + col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int splits, int C,
-                                                     float* __restrict__ out) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= C) return;
-    float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += partial[(long)i * C + col];
-    out[col] = s;
-}
 
 // ---- fold LayerNorm affine into the next Linear: Wf[n][k] = W[n][k] * gamma[k], bf[n] = b[n] + W[n].beta
 // grid.x = heads * R rows (one wave per row), W [heads][R][K], gamma/beta [heads][K]
@@ -524,19 +500,6 @@ int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, cons
     else
         hipLaunchKernelGGL(normalize_bwd_kernel<MAXCW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
     AS_LAUNCH_CHECK("normalize_bwd");
-    return 0;
-}
-int as_colsum_splits(long rows) {
-    long s = (rows + 63) / 64;
-    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
-}
-int as_colsum(const float* x, long rows, int C, long ldx, float* out, float* partial, hipStream_t st) {
-    const int splits = as_colsum_splits(rows);
-    const int rps = (int)((rows + splits - 1) / splits);
-    hipLaunchKernelGGL(colsum_stage1, dim3(as_cdiv(C, 64), splits), dim3(256), 0, st, x, rows, C, ldx, partial, rps);
-    AS_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(as_cdiv(C, 256)), dim3(256), 0, st, partial, splits, C, out);
-    AS_LAUNCH_CHECK("colsum_stage2");
     return 0;
 }
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
