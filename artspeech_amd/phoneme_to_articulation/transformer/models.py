@@ -91,7 +91,9 @@ def _reference_order_state(vocab_size, A, d, heads, L, nf):
     return sd
 
 
-LAST_ONLY = os.environ.get("ARTSPEECH_GENERATE_FULL_LAST") is None  # ablation switch for generate()'s last-layer restriction
+# generate(): reuse the step-invariant memory-side K/V and restrict the last layer to the newest frame (both exact);
+# ARTSPEECH_GENERATE_PLAIN=1 (or setting this to False) re-decodes everything like the reference, for A/B timing.
+GENERATE_SAVINGS = os.environ.get("ARTSPEECH_GENERATE_PLAIN") is None
 
 
 class ArtSpeechTransformer(nn.Module):
@@ -411,9 +413,12 @@ class ArtSpeechTransformer(nn.Module):
             memory = self._encode(src.long(), kpm, self._zero_padded())
             tgt = self.start.repeat(B, 1, 1, 1)
             # the only step-invariant part of the (unmasked, hence non-causal) re-decoding: the memory side of the cross blocks
-            mem_hat = Normalize.apply(memory)[None]
-            memory_kv = [self._memory_kv(l, mem_hat) for l in range(self.num_layers)]
+            memory_kv = None
+            if GENERATE_SAVINGS:
+                mem_hat = Normalize.apply(memory)[None]
+                memory_kv = [self._memory_kv(l, mem_hat) for l in range(self.num_layers)]
             for _ in range(T):
-                nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm, memory_kv=memory_kv, last_only=LAST_ONLY)
+                nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm, memory_kv=memory_kv,
+                                              last_only=GENERATE_SAVINGS)
                 tgt = torch.cat([tgt, nxt[:, -1:].reshape(B, 1, self.num_articulators, self.num_feat)], dim=1)
             return tgt.reshape(B, T + 1, self.num_articulators, 2, self.num_feat // 2)[:, 1:]
