@@ -75,6 +75,21 @@ def test_generate_matches_reference_fixture(small, dev):
     assert err.max() < 2e-5, err.max()
 
 
+def test_generate_savings_are_exact(small, dev):
+    """Memory-side K/V computed once + last layer restricted to the newest frame == re-decoding everything."""
+    from artspeech_amd.phoneme_to_articulation.transformer import models as M
+    model, g, _ = small
+    src, kpm = _t(g["tokens"], dev, torch.int64), _t(g["src_kpm"], dev)
+    try:
+        M.GENERATE_SAVINGS = False
+        plain = model.generate(src, kpm)
+        M.GENERATE_SAVINGS = True
+        fast = model.generate(src, kpm)
+    finally:
+        M.GENERATE_SAVINGS = True
+    assert (plain - fast).abs().max() < 2e-6  # same arithmetic per element; only the GEMM tile shapes differ
+
+
 def test_medium_config_vs_oracle(dev):
     """d=64, 4 heads, 2 layers, A=4, T=24, ragged: against the fp64 oracle (both encoder modes)."""
     from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
