@@ -58,3 +58,58 @@ def forward(params, tokens, lengths, lstm):
         if relu:
             x = np.maximum(x, 0)
     return np.tanh(x)
+
+
+# ---- autoencoders and the critical-distance loss of the same method ------------------------------------------------------
+def _mlp(x, p, prefix):
+    """nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) -- Encoder / Decoder (models/autoencoder.py:83-112)."""
+    for idx, relu in ((0, True), (2, True), (4, False)):
+        x = x @ p[f"{prefix}{idx}.weight"].T + p[f"{prefix}{idx}.bias"]
+        if relu:
+            x = np.maximum(x, 0)
+    return x
+
+
+def _indices(comps):
+    """make_indices_dict (helpers.py:94-114) on {articulator: n_components} in insertion order."""
+    out, start = {}, 0
+    for name, n in comps.items():
+        out[name] = list(range(start, start + n))
+        start += n
+    return out
+
+
+def autoencoder_forward(params, x, comps):
+    """MultiArticulatorAutoencoder.forward (models/autoencoder.py:253-260): x (bs, A, F), channels in sorted-name order ->
+    (outputs (bs, A, F), latent (bs, latent_size)); a latent index takes the max over the encoders that own it (:155-173)."""
+    p = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    x = np.asarray(x, np.float64)
+    idx = _indices(comps)
+    names = sorted(idx)
+    latent_size = 1 + max(i for v in idx.values() for i in v)
+    spaces = np.full((x.shape[0], len(names), latent_size), -np.inf)
+    for i, name in enumerate(names):
+        spaces[:, i, idx[name]] = _mlp(x[:, i], p, f"encoders.encoders.{name}.encoder.")
+    latent = np.tanh(spaces.max(1))
+    outs = np.stack([_mlp(latent[:, idx[name]], p, f"decoders.decoders.{name}.decoder.") for name in names], 1)
+    return outs, latent
+
+
+def critical_loss(shapes, reference_arrays, mask, TVs, articulators):
+    """CriticalLoss.forward (losses.py:52-99) without denormalisation: per tract variable the minimum pairwise distance
+    between its two articulators' contours per frame, mean over mask == 1.  shapes (bs, T, A, 2, N)."""
+    pairs = {"LA": ("lower-lip", "upper-lip"), "TTCD": ("tongue", "upper-incisor"), "TBCD": ("tongue", "upper-incisor"),
+             "VEL": ("soft-palate", "pharynx")}
+    shapes = np.asarray(shapes, np.float64)
+    arts = list(articulators)
+    if "upper-incisor" not in arts:
+        arts = sorted(arts + ["upper-incisor"])
+        r = arts.index("upper-incisor")
+        shapes = np.concatenate([shapes[:, :, :r], np.asarray(reference_arrays, np.float64), shapes[:, :, r:]], 2)
+    vals = []
+    for tv in sorted(TVs):
+        a, b = (shapes[:, :, arts.index(n)] for n in pairs[tv])          # (bs, T, 2, N)
+        d = np.sqrt(((a[..., :, None] - b[..., None, :]) ** 2).sum(-3))  # (bs, T, N, N)
+        vals.append(d.reshape(*d.shape[:2], -1).min(-1))
+    crit = np.stack(vals, 1)                                              # (bs, n_TVs, T)
+    return crit[np.asarray(mask) == 1].mean()

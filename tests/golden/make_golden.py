@@ -49,11 +49,12 @@ def _load(name, relpath):
 
 
 def install_shims():
-    _shim("funcy", lmap=lambda f, *s: list(map(f, *s)), lfilter=lambda f, s: list(filter(f, s)))
+    _shim("funcy", lmap=lambda f, *s: list(map(f, *s)), lfilter=lambda f, s: list(filter(f, s)),
+          flatten=lambda seq: [x for sub in seq for x in sub])
     vt = _shim(
         "vt_tools",
         LOWER_LIP="lower-lip", PHARYNX="pharynx", SOFT_PALATE_MIDLINE="soft-palate-midline",
-        TONGUE="tongue", UPPER_LIP="upper-lip", UPPER_INCISOR="upper-incisor",
+        TONGUE="tongue", UPPER_LIP="upper-lip", UPPER_INCISOR="upper-incisor", SOFT_PALATE="soft-palate",
     )
     vt.metrics = _shim(
         "vt_tools.metrics",
@@ -395,6 +396,41 @@ def gen_principal_components(pc_rnn):
     return out
 
 
+def gen_pc_autoencoder(ae, losses):
+    """MultiArticulatorAutoencoder (principal_components/models/autoencoder.py:216-260) forward + parameter gradients, and
+    CriticalLoss (losses.py:23-99) value + gradient w.r.t. the predicted shapes (N = 12 points <= 25: cdist computes the
+    differences directly, no matmul expansion)."""
+    torch.manual_seed(51)
+    comps = {"tongue": 4, "lower-lip": 3, "upper-lip": 2}
+    model = ae.MultiArticulatorAutoencoder(in_features=20, indices_dict=comps, hidden_features=16)
+    init_abs_sum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    x = torch.rand(6, 3, 20)
+    out, latent = model(x)
+    dout, dlat = torch.rand_like(out), torch.rand_like(latent)
+    ((out * dout).sum() + (latent * dlat).sum()).backward()
+    arrays = dict(x=x.numpy(), out=out.detach().numpy(), latent=latent.detach().numpy(), dout=dout.numpy(), dlat=dlat.numpy(),
+                  comps=np.array(list(comps.values()), dtype=np.int64))
+    arrays.update(sd_to_np("w.", model.state_dict()))
+    arrays.update({"g." + k: p.grad.numpy() for k, p in model.named_parameters()})
+    save("pc_autoencoder", **arrays)
+
+    torch.manual_seed(52)
+    arts = ["lower-lip", "tongue", "upper-lip"]          # sorted, upper incisor injected from the reference contour
+    crit = losses.CriticalLoss(["TTCD", "LA"], list(arts))
+    shapes = torch.rand(2, 5, 3, 2, 12, requires_grad=True)
+    targets = torch.rand(2, 5, 3, 2, 12)
+    ref = torch.rand(2, 5, 1, 2, 12)
+    mask = (torch.rand(2, 2, 5) > 0.4).float()
+    mask[0, 0, 0] = 1.0
+    loss = crit(shapes, targets, ref, mask)
+    loss.backward()
+    save("pc_critical_loss", shapes=shapes.detach().numpy(), targets=targets.numpy(), ref=ref.numpy(), mask=mask.numpy(),
+         loss=np.array(loss.item()), dshapes=shapes.grad.numpy())
+    return {"pc_autoencoder": dict(out_sum=float(out.sum()), seed=51, init_abs_sum=init_abs_sum, params=model.total_parameters,
+                                   comps=comps),
+            "pc_critical_loss": dict(loss=float(loss))}
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)  # for `settings`, `helpers`
@@ -450,6 +486,20 @@ def main():
     pkg.RNNType = _load("ref_p2a_init", "phoneme_to_articulation/__init__.py").RNNType
     pc_rnn = _load("ref_pc_rnn", "phoneme_to_articulation/principal_components/models/rnn.py")
     checks.update(gen_principal_components(pc_rnn))
+    # autoencoders + critical loss: register the reference's package modules under their own names, then load them
+    pcpkg = types.ModuleType("phoneme_to_articulation.principal_components")
+    pcpkg.__path__ = [os.path.join(REF, "phoneme_to_articulation/principal_components")]
+    sys.modules["phoneme_to_articulation.principal_components"] = pcpkg
+    mpkg = types.ModuleType("phoneme_to_articulation.principal_components.models")
+    mpkg.__path__ = [os.path.join(REF, "phoneme_to_articulation/principal_components/models")]
+    sys.modules["phoneme_to_articulation.principal_components.models"] = mpkg
+    ae = _load("phoneme_to_articulation.principal_components.models.autoencoder",
+               "phoneme_to_articulation/principal_components/models/autoencoder.py")
+    for name in ("Encoder", "Decoder", "MultiEncoder", "MultiDecoder"):
+        setattr(mpkg, name, getattr(ae, name))
+    _load("phoneme_to_articulation.principal_components.transforms", "phoneme_to_articulation/principal_components/transforms.py")
+    pc_losses = _load("phoneme_to_articulation.principal_components.losses", "phoneme_to_articulation/principal_components/losses.py")
+    checks.update(gen_pc_autoencoder(ae, pc_losses))
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
     print(json.dumps(checks, indent=1))

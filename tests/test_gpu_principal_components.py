@@ -120,3 +120,63 @@ def test_full_size_backward_matches_finite_difference(lstm, dev):
                 p.sub_(sgn * eps * d)
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(numeric - analytic) < 1e-2 * max(abs(analytic), 1e-3) + 2e-5, (numeric, analytic)
+
+
+def test_autoencoder_matches_reference_fixture_forward_and_gradients(dev):
+    from artspeech_amd.phoneme_to_articulation.principal_components.models import MultiArticulatorAutoencoder
+    g = load_golden("pc_autoencoder")
+    w, grads = split_wg(g)
+    comps = dict(zip(["tongue", "lower-lip", "upper-lip"], (int(c) for c in g["comps"])))
+    m = MultiArticulatorAutoencoder(in_features=20, indices_dict=comps, hidden_features=16)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    m.to(dev)
+    out, latent = m(torch.from_numpy(g["x"]).to(dev))
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 2e-6
+    assert np.abs(latent.detach().cpu().numpy() - g["latent"]).max() < 2e-6
+    ((out * torch.from_numpy(g["dout"]).to(dev)).sum() + (latent * torch.from_numpy(g["dlat"]).to(dev)).sum()).backward()
+    for k, p in m.named_parameters():
+        assert np.abs(p.grad.cpu().numpy() - grads[k]).max() < 1e-5 * max(1.0, np.abs(grads[k]).max()), k
+
+
+def test_critical_loss_matches_reference_fixture_and_oracle(dev):
+    from artspeech_amd.phoneme_to_articulation.principal_components.losses import CriticalLoss
+    c = load_golden("pc_critical_loss")
+    arts = ["lower-lip", "tongue", "upper-lip"]
+    crit = CriticalLoss(["TTCD", "LA"], list(arts))
+    shapes = torch.from_numpy(c["shapes"]).to(dev).requires_grad_(True)
+    loss = crit(shapes, torch.from_numpy(c["targets"]).to(dev), torch.from_numpy(c["ref"]).to(dev), torch.from_numpy(c["mask"]).to(dev))
+    assert abs(float(loss) - float(c["loss"])) < 1e-7
+    loss.backward()
+    assert np.abs(shapes.grad.cpu().numpy() - c["dshapes"]).max() < 1e-6
+    assert float(CriticalLoss([], arts)(shapes, shapes, None, None)) == 0.0
+    # 50-point contours, four variables, against the oracle (the reference's cdist would use its matmul expansion here)
+    rng = np.random.default_rng(5)
+    arts = ["lower-lip", "pharynx", "soft-palate", "tongue", "upper-incisor", "upper-lip"]
+    big = rng.random((3, 7, 6, 2, 50), dtype=np.float32)
+    mask = (rng.random((3, 4, 7)) > 0.3).astype(np.float32)
+    got = CriticalLoss(["LA", "TTCD", "TBCD", "VEL"], arts)(torch.from_numpy(big).to(dev), torch.from_numpy(big).to(dev), None,
+                                                             torch.from_numpy(mask).to(dev))
+    want = PO.critical_loss(big, None, mask, ["LA", "TTCD", "TBCD", "VEL"], arts)
+    assert abs(float(got) - want) < 1e-6
+
+
+def test_wrapper_decodes_components_to_shapes(dev):
+    """PrincipalComponentsArtSpeechWrapper: rnn -> MultiDecoder -> per-articulator denormalisation."""
+    from artspeech_amd.phoneme_to_articulation.principal_components.models import (MultiDecoder, PrincipalComponentsArtSpeech,
+                                                                                    PrincipalComponentsArtSpeechWrapper)
+    torch.manual_seed(9)
+    comps = {"tongue": 4, "lower-lip": 3}
+    rnn = PrincipalComponentsArtSpeech(13, comps, embed_dim=16, hidden_size=32, rnn="lstm").to(dev)
+    dec = MultiDecoder(comps, in_features=20, hidden_features=16).to(dev)
+    denorm = {"tongue": lambda a: a * 2.0 + 0.5, "lower-lip": lambda a: a - 1.0}
+    model = PrincipalComponentsArtSpeechWrapper(rnn, dec, denorm).eval()
+    tokens, lengths = torch.randint(1, 13, (3, 6), device=dev), [6, 4, 2]
+    with torch.no_grad():
+        out = model(tokens, lengths)
+        z = rnn(tokens, lengths)
+    assert out.shape == (3, 6, 2, 2, 10)
+    w = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dec.state_dict().items()}
+    zz = z.cpu().numpy().astype(np.float64)
+    for i, (name, idx, f) in enumerate((("lower-lip", [4, 5, 6], lambda a: a - 1.0), ("tongue", [0, 1, 2, 3], lambda a: a * 2.0 + 0.5))):
+        want = f(PO._mlp(zz[..., idx], w, f"decoders.{name}.decoder.").reshape(3, 6, 2, 10))
+        assert np.abs(out[:, :, i].cpu().numpy() - want).max() < 1e-5

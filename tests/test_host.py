@@ -318,3 +318,20 @@ def test_transformer_seeded_init_matches_reference():
     assert abs(init - chk["init_abs_sum"]) < 1e-9 * chk["init_abs_sum"]
     assert torch.equal(sd["decoder.layers.0.feed_forward.1.weight"], sd["decoder.layers.1.feed_forward.1.weight"])
     assert torch.equal(sd["encoder.layers.0.linear1.weight"], sd["encoder.layers.1.linear1.weight"])
+
+
+def test_pc_autoencoder_keys_and_seeded_init_match_reference():
+    import json
+    from conftest import GOLDEN
+    from artspeech_amd.phoneme_to_articulation.principal_components.models import MultiArticulatorAutoencoder
+    g = load_golden("pc_autoencoder")
+    w, _ = split_wg(g)
+    with open(os.path.join(GOLDEN, "checksums.json")) as f:
+        chk = json.load(f)["cases"]["pc_autoencoder"]
+    torch.manual_seed(chk["seed"])
+    m = MultiArticulatorAutoencoder(in_features=20, indices_dict=chk["comps"], hidden_features=16)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(w.keys()) and all(tuple(sd[k].shape) == w[k].shape for k in w)
+    assert m.total_parameters == chk["params"] and m.latent_size == 9
+    init = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    assert abs(init - chk["init_abs_sum"]) < 1e-9 * chk["init_abs_sum"]

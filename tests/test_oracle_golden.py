@@ -181,3 +181,15 @@ def test_principal_components_oracle_matches_reference_fixture(name):
     w, _ = split_wg(g)
     out = PO.forward(w, g["tokens"], g["lengths"], lstm=bool(g["cfg"][4]))
     assert out.shape == g["out"].shape and np.abs(out - g["out"]).max() < 2e-6
+
+
+def test_pc_autoencoder_and_critical_loss_oracle_match_reference_fixtures():
+    from oracle import principal_components_oracle as PO
+    g = load_golden("pc_autoencoder")
+    w, _ = split_wg(g)
+    comps = dict(zip(["tongue", "lower-lip", "upper-lip"], (int(c) for c in g["comps"])))
+    out, latent = PO.autoencoder_forward(w, g["x"], comps)
+    assert np.abs(out - g["out"]).max() < 2e-6 and np.abs(latent - g["latent"]).max() < 2e-6
+    c = load_golden("pc_critical_loss")
+    loss = PO.critical_loss(c["shapes"], c["ref"], c["mask"], ["TTCD", "LA"], ["lower-lip", "tongue", "upper-lip"])
+    assert abs(loss - float(c["loss"])) < 1e-7
