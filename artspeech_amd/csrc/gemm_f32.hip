@@ -587,7 +587,33 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     if (force && !strcmp(force, "128x128")) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "64x128")) return launch<64, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "128x64")) return launch<128, 64>(k, g->batch, a_kc, b_kc, st);
-    if (!force && big >= 256 && g->N >= 128) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
+    if (!force && big >= 256 && g->N >= 128) {
+        // 128x128 tiles that do not fill the resident slots (3 per CU) with a long reduction: split K so that the persistent
+        // workgroups get equal shares (measured: 440 tiles, K = 6400 run at 75 TF/s, 768 tiles of the same shape at 100)
+        static const int slots = resident_blocks(gemm_f32_kernel<128, 128, true, true, true>);
+        if (g->splitk_ws && !grouped && big < slots && g->K >= 2048 && !g->bias && g->act == 0) {
+            const long per = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
+            long best = 1;
+            double best_cost = 1.0;  // rounds of work per workgroup, in units of the unsplit tile time
+            for (long sk = 2; sk <= 8 && sk * per <= g->splitk_ws_floats; ++sk) {
+                const double cost = (double)((big * sk + slots - 1) / slots) / sk + 0.02 * sk;  // + slab traffic
+                if (cost < best_cost - 1e-9) best_cost = cost, best = sk;
+            }
+            if (best > 1) {
+                k.kchunk = (int)as_round_up(as_cdiv(g->K, best), BK);
+                k.splitk = as_cdiv(g->K, k.kchunk);
+                k.slab = g->splitk_ws;
+                AS_TRY((launch<128, 128>(k, g->batch, a_kc, b_kc, st)));
+                const long total = per;
+                long blocks = (total + 255) / 256;
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, k);
+                AS_LAUNCH_CHECK("as_gemm_f32(splitk reduce)");
+                return 0;
+            }
+        }
+        return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
+    }
     // few output tiles and a long reduction (weight gradients): split K over workgroups
     const long tiles = (long)as_cdiv(g->M, 64) * as_cdiv(g->N, 64) * g->batch;
     if (g->splitk_ws && !grouped && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {

@@ -12,7 +12,12 @@ from artspeech_amd import _lib  # noqa: E402
 L = _lib.lib()
 dev = torch.device("cuda:0")
 st = _lib.stream_ptr()
-for (G, M, N, K) in [(110, 256, 256, 6400), (11, 256, 256, 6400), (110, 256, 256, 3200), (11, 256, 2560, 6400)]:
+slab = torch.empty(int(os.environ.get("SLAB_MFLOATS", "64")) << 20, device=dev)  # split-K workspace
+SHAPES = [(110, 256, 256, 6400), (11, 256, 256, 6400), (110, 256, 256, 3200), (11, 256, 2560, 6400), (192, 256, 256, 6400),
+                     (384, 256, 256, 3200)]
+if os.environ.get("TN_SHAPE"):  # e.g. TN_SHAPE=0 for a single (profiled) shape
+    SHAPES = [SHAPES[int(os.environ["TN_SHAPE"])]]
+for (G, M, N, K) in SHAPES:
     a = torch.randn(G, K, M, device=dev)
     b = torch.randn(G, K, N, device=dev)
     c = torch.empty(G, M, N, device=dev)
@@ -23,6 +28,7 @@ for (G, M, N, K) in [(110, 256, 256, 6400), (11, 256, 256, 6400), (110, 256, 256
     g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = 1, M, 1, N, N
     g.batch, g.a_batch, g.b_batch, g.c_batch = G, K * M, K * N, M * N
     g.colsum, g.colsum_batch = db.data_ptr(), M
+    g.splitk_ws, g.splitk_ws_floats = slab.data_ptr(), slab.numel()
     for _ in range(2):
         _lib.check(L.as_gemm_f32(C.byref(g), st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
