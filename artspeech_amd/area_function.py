@@ -99,3 +99,34 @@ def load_air_columns(directory, frame_ids, device=None):
     stack = np.stack([np.load(os.path.join(directory, f"{frame_id}.npy")) for frame_id in frame_ids]).astype(np.float64)
     t = torch.from_numpy(stack)
     return t.to(device) if device is not None else t
+
+
+def intersect_semipolar_grid_batched(air_column, semipolar_grid):
+    """air_column (frames, 2, 2, Nw) float64 on the GPU (internal wall first), semipolar_grid (n_lines, grid_res, 2) ->
+    flags int32 (frames, n_lines) (bit 0 / 1: internal / external wall crossed; 0 = line skipped by the reference; bit 2:
+    more than 16 crossings of one wall), internal / external points float64 (frames, n_lines, 2).  One wave per
+    (frame, grid line); see ``intersect_semipolar_grid`` for the selection rule."""
+    _lib.require_gpu(air_column, "air_column")
+    air = air_column.to(torch.float64).contiguous()
+    grid = torch.as_tensor(np.asarray(semipolar_grid, dtype=np.float64)).to(air.device).contiguous()
+    frames, _, _, n_pts = air.shape
+    n_lines, grid_res, _ = grid.shape
+    flags = torch.empty((frames, n_lines), dtype=torch.int32, device=air.device)
+    p_int = torch.empty((frames, n_lines, 2), dtype=torch.float64, device=air.device)
+    p_ext = torch.empty_like(p_int)
+    _lib.check(_lib.lib().as_intersect_semipolar_grid(_lib.ptr(air), _lib.ptr(grid), frames, n_pts, n_lines, grid_res, _lib.ptr(flags),
+                                                      _lib.ptr(p_int), _lib.ptr(p_ext), _lib.stream_ptr()), "as_intersect_semipolar_grid")
+    return flags, p_int, p_ext
+
+
+def intersect_semipolar_grid(internal_wall, external_wall, semipolar_grid):
+    """Section points of one vocal tract: for every grid line that crosses a wall, the crossing closest to the other wall's
+    crossings; a wall that the line does not cross contributes its end point nearer to ... the external wall's ends
+    (reference area_function.py:175-223, quirk of :211 included).  Walls (Nw, 2) -> (internal (K, 2), external (K, 2))
+    numpy float64 over the K lines with contact, in grid order -- the inputs of ``area_function``."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("artspeech_amd.area_function needs an MI355X device; there is no CPU path")
+    air = torch.from_numpy(np.array([np.asarray(internal_wall, dtype=np.float64).T, np.asarray(external_wall, dtype=np.float64).T]))
+    flags, p_int, p_ext = intersect_semipolar_grid_batched(air[None].cuda(), semipolar_grid)
+    keep = (flags[0] & 3).cpu().numpy() != 0
+    return p_int[0].cpu().numpy()[keep], p_ext[0].cpu().numpy()[keep]

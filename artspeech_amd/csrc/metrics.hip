@@ -292,6 +292,115 @@ __global__ __launch_bounds__(256) void resample_kernel(const double* __restrict_
     out[(f * 2 + 1) * n_samples + s] = (float)y;
 }
 
+// ---------------------------------------------------------------- wall / semipolar-grid intersection (fp64)
+// intersect_semipolar_grid (area_function.py:175-223): one wave per (frame, grid line).  The lanes test all (grid segment,
+// wall segment) pairs of both walls (p + t r = q + u s, half-open parameter ranges so that a junction hit is reported
+// once), hits are collected in LDS with their position along the grid line, lane 0 orders them along the line and applies
+// the reference's selection: the wall's hit closest to the other wall's hits (first minimum of the distance matrix in
+// row-major order), or -- when the other wall is not crossed -- closest to the EXTERNAL wall's end points, whose nearer
+// end then stands in for the missing point (also in the external branch, :211).
+constexpr int GI_MAXP = 16;  // hits kept per wall and grid line
+
+struct GiHit { double key; double x, y; int ws; };
+
+__device__ __forceinline__ int gi_argmin(const GiHit* a, int na, const double (*b)[2], int nb, int* j_out) {
+    double best = 0.0;
+    int bi = 0, bj = 0;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            const double dx = __dsub_rn(a[i].x, b[j][0]), dy = __dsub_rn(a[i].y, b[j][1]);
+            const double d = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+            if ((i == 0 && j == 0) || d < best) best = d, bi = i, bj = j;
+        }
+    *j_out = bj;
+    return bi;
+}
+
+__global__ __launch_bounds__(256) void grid_intersect_kernel(const double* __restrict__ air, const double* __restrict__ grid,
+                                                             long frames, int Nw, int L, int G, int* __restrict__ flags,
+                                                             double* __restrict__ p_int, double* __restrict__ p_ext) {
+    __shared__ GiHit hits[4][2][GI_MAXP];
+    __shared__ int cnt[4][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + wave;
+    const bool live = item < frames * L;
+    const long f = live ? item / L : 0;
+    const int l = live ? (int)(item - f * L) : 0;
+    if (lane < 2) cnt[wave][lane] = 0;
+    __syncthreads();
+    const double* gl = grid + (long)l * G * 2;
+    const int pairs = (G - 1) * (Nw - 1);
+    if (live) {
+        for (int wall = 0; wall < 2; ++wall) {
+            const double* wx = air + (f * 2 + wall) * 2 * Nw;  // x coordinates; y at + Nw
+            const double* wy = wx + Nw;
+            for (int idx = lane; idx < pairs; idx += 64) {
+                const int gs = idx / (Nw - 1), ws = idx - gs * (Nw - 1);
+                const double px = gl[2 * gs], py = gl[2 * gs + 1];
+                const double rx = __dsub_rn(gl[2 * gs + 2], px), ry = __dsub_rn(gl[2 * gs + 3], py);
+                const double qx = wx[ws], qy = wy[ws];
+                const double sx = __dsub_rn(wx[ws + 1], qx), sy = __dsub_rn(wy[ws + 1], qy);
+                const double den = __dsub_rn(__dmul_rn(rx, sy), __dmul_rn(ry, sx));
+                if (den == 0.0) continue;
+                const double dqx = __dsub_rn(qx, px), dqy = __dsub_rn(qy, py);
+                const double t = __ddiv_rn(__dsub_rn(__dmul_rn(dqx, sy), __dmul_rn(dqy, sx)), den);
+                const double u = __ddiv_rn(__dsub_rn(__dmul_rn(dqx, ry), __dmul_rn(dqy, rx)), den);
+                const bool t_ok = 0.0 <= t && (t < 1.0 || (gs == G - 2 && t <= 1.0));
+                const bool u_ok = 0.0 <= u && (u < 1.0 || (ws == Nw - 2 && u <= 1.0));
+                if (t_ok && u_ok) {
+                    const int slot = atomicAdd(&cnt[wave][wall], 1);
+                    if (slot < GI_MAXP) {
+                        GiHit h;
+                        h.key = __dadd_rn((double)gs, t);
+                        h.x = __dadd_rn(px, __dmul_rn(t, rx));
+                        h.y = __dadd_rn(py, __dmul_rn(t, ry));
+                        h.ws = ws;
+                        hits[wave][wall][slot] = h;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!live || lane != 0) return;
+    int n[2];
+    int overflow = 0;
+    for (int wall = 0; wall < 2; ++wall) {
+        n[wall] = cnt[wave][wall];
+        if (n[wall] > GI_MAXP) n[wall] = GI_MAXP, overflow = 4;
+        GiHit* h = hits[wave][wall];
+        for (int i = 1; i < n[wall]; ++i) {  // order along the grid line (then along the wall): insertion sort, <= 16 items
+            const GiHit v = h[i];
+            int j = i - 1;
+            while (j >= 0 && (h[j].key > v.key || (h[j].key == v.key && h[j].ws > v.ws))) { h[j + 1] = h[j]; --j; }
+            h[j + 1] = v;
+        }
+    }
+    const double* ix = air + (f * 2 + 0) * 2 * Nw;
+    const double* ex = air + (f * 2 + 1) * 2 * Nw;
+    const double ends[2][2] = {{ex[0], ex[Nw]}, {ex[Nw - 1], ex[2 * Nw - 1]}};  // the external wall's first / last point
+    const bool ic = n[0] > 0, ec = n[1] > 0;
+    double oi[2] = {0.0, 0.0}, oe[2] = {0.0, 0.0};
+    double other[GI_MAXP][2];
+    if (ic) {
+        int nb = 2, jm;
+        if (ec) { nb = n[1]; for (int j = 0; j < nb; ++j) other[j][0] = hits[wave][1][j].x, other[j][1] = hits[wave][1][j].y; }
+        const int im = gi_argmin(hits[wave][0], n[0], ec ? other : ends, nb, &jm);
+        oi[0] = hits[wave][0][im].x; oi[1] = hits[wave][0][im].y;
+        if (!ec) { const int e = jm ? Nw - 1 : 0; oe[0] = ex[e]; oe[1] = ex[Nw + e]; }
+    }
+    if (ec) {
+        int nb = 2, jm;
+        if (ic) { nb = n[0]; for (int j = 0; j < nb; ++j) other[j][0] = hits[wave][0][j].x, other[j][1] = hits[wave][0][j].y; }
+        const int im = gi_argmin(hits[wave][1], n[1], ic ? other : ends, nb, &jm);
+        oe[0] = hits[wave][1][im].x; oe[1] = hits[wave][1][im].y;
+        if (!ic) { const int e = jm ? Nw - 1 : 0; oi[0] = ix[e]; oi[1] = ix[Nw + e]; }
+    }
+    flags[item] = (ic ? 1 : 0) | (ec ? 2 : 0) | overflow;
+    p_int[2 * item] = oi[0]; p_int[2 * item + 1] = oi[1];
+    p_ext[2 * item] = oe[0]; p_ext[2 * item + 1] = oe[1];
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -388,5 +497,16 @@ extern "C" int as_evenly_spaced_fx(const double* x, const double* fx, int64_t fr
     hipLaunchKernelGGL(resample_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fx, (long)frames, n_pts,
                        n_samples, out);
     AS_LAUNCH_CHECK("as_evenly_spaced_fx");
+    return 0;
+}
+
+extern "C" int as_intersect_semipolar_grid(const double* air_column, const double* grid, int64_t frames, int32_t n_pts, int32_t n_lines,
+                                           int32_t grid_res, int32_t* flags, double* p_int, double* p_ext, void* stream) {
+    AS_REQUIRE(air_column && grid && flags && p_int && p_ext && frames > 0 && n_pts >= 2 && n_lines > 0 && grid_res >= 2, AS_ERR_BAD_ARG,
+               "as_intersect_semipolar_grid: bad argument");
+    const long items = (long)frames * n_lines;
+    hipLaunchKernelGGL(grid_intersect_kernel, dim3(as_cdiv(items, 4)), dim3(256), 0, (hipStream_t)stream, air_column, grid, (long)frames,
+                       n_pts, n_lines, grid_res, flags, p_int, p_ext);
+    AS_LAUNCH_CHECK("as_intersect_semipolar_grid");
     return 0;
 }

@@ -310,6 +310,15 @@ int as_gelu(const float* x, float* y, int64_t n, void* stream);
 int as_gru_unidir_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int32_t B, int32_t T,
                       int32_t H, float* y, void* stream);
 
+/* intersect_semipolar_grid (area_function.py:175-223), float64, batched over frames: air_column [frames][2 walls][2][n_pts]
+ * (internal wall first, x row then y row -- the air-column file layout), grid [n_lines][grid_res][2].  For every frame and
+ * grid line: flags bit 0 / 1 = the internal / external wall is crossed (0: the reference skips the line), bit 2 = more than
+ * 16 crossings of one wall (extra ones dropped); p_int / p_ext [frames][n_lines][2] = the selected point on each wall (the
+ * wall's own end point when that wall is not crossed).  Intersections are float64 segment tests ordered along the grid
+ * line; the reference computes them with shapely/GEOS (parity unpinned). */
+int as_intersect_semipolar_grid(const double* air_column, const double* grid, int64_t frames, int32_t n_pts, int32_t n_lines,
+                                int32_t grid_res, int32_t* flags, double* p_int, double* p_ext, void* stream);
+
 /* torch.optim.Adam semantics (L2 weight decay added to the gradient; train_phoneme_to_articulation.py:
  * 177-181) over flat buffers, one launch.  step is the 1-based step count after this update. */
 int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -7,7 +7,7 @@ It is a from-the-math numpy restatement (explicit forward AND hand-derived backw
 the reference's algorithm.  Every function cites the reference lines it follows (paths relative to the
 reference repository root).  Parity status: PINNED -- ``tests/test_oracle_golden.py`` checks every
 function against fixtures in ``tests/golden/`` that were produced by running the reference itself
-(``tests/golden/make_golden.py``), except ``evenly_spaced_fx`` (shapely absent => unpinned) and the
+(``tests/golden/make_golden.py``), except ``evenly_spaced_fx`` / ``intersect_semipolar_grid`` (shapely absent => parity unpinned) and the
 ``vt_tools.metrics.euclidean`` semantic assumed by the area-function fixture.
 
 All functions take/return numpy arrays.  ``dtype`` selects the arithmetic type: float64 (default,
@@ -437,3 +437,64 @@ def build_semipolar_grid(center, theta_rad, omega_rad, linear_step, polar_step_r
         for pi, pe in zip(seq_int, seq_ext):
             lines.append(np.stack([np.linspace(pi[0], pe[0], grid_res), np.linspace(pi[1], pe[1], grid_res)], 1))
     return np.array(lines)
+
+
+def _polyline_intersections(line, wall):
+    """Intersection points of two polylines ((G, 2) and (W, 2) float64), ordered along `line`.  Segment pair test in
+    float64: p + t r = q + u s with r x s != 0; a hit at a junction of two consecutive segments is attributed to the
+    segment where the parameter is 0 (half-open [0, 1) except on the last segment), so no point is reported twice."""
+    pts = []
+    G, W = len(line), len(wall)
+    for gs in range(G - 1):
+        p, r = line[gs], line[gs + 1] - line[gs]
+        for ws in range(W - 1):
+            q, s = wall[ws], wall[ws + 1] - wall[ws]
+            den = r[0] * s[1] - r[1] * s[0]
+            if den == 0.0:
+                continue  # parallel (collinear overlaps are not points; the reference would fail on them)
+            dq = q - p
+            t = (dq[0] * s[1] - dq[1] * s[0]) / den
+            u = (dq[0] * r[1] - dq[1] * r[0]) / den
+            t_ok = 0.0 <= t and (t < 1.0 or (gs == G - 2 and t <= 1.0))
+            u_ok = 0.0 <= u and (u < 1.0 or (ws == W - 2 and u <= 1.0))
+            if t_ok and u_ok:
+                pts.append((gs + t, ws, p + t * r))
+    pts.sort(key=lambda e: (e[0], e[1]))
+    return np.array([e[2] for e in pts]).reshape(-1, 2)
+
+
+def _argmin_matrix(a, b):
+    """argmatrix(distance_matrix(a, b), "min") (area_function.py:160-172): first minimum in row-major order."""
+    d = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
+    k = int(np.argmin(d))
+    return k // d.shape[1], k % d.shape[1]
+
+
+def intersect_semipolar_grid(internal_wall, external_wall, semipolar_grid):
+    """intersect_semipolar_grid (area_function.py:175-223): for every grid line that touches a wall, the wall's intersection
+    point closest to the other wall's intersections (or, when the other wall is not crossed, closest to the EXTERNAL wall's
+    end points -- also in the external branch, :211 -- whose nearer end then stands in for the missing point).
+    PARITY UNPINNED: the reference computes the intersections with shapely/GEOS (absent here); this restates them with the
+    float64 segment test above, points ordered along the grid line (the order only decides exact distance ties).
+    Returns (flags (L,), internal (L, 2), external (L, 2)); flags bit 0 / 1 = internal / external wall crossed; lines with
+    flags 0 are the ones the reference skips."""
+    internal_wall, external_wall = np.asarray(internal_wall, np.float64), np.asarray(external_wall, np.float64)
+    grid = np.asarray(semipolar_grid, np.float64)
+    L = len(grid)
+    flags, pi, pe = np.zeros(L, np.int32), np.zeros((L, 2)), np.zeros((L, 2))
+    default = np.array([external_wall[0], external_wall[-1]])
+    for l in range(L):
+        li, le = _polyline_intersections(grid[l], internal_wall), _polyline_intersections(grid[l], external_wall)
+        ic, ec = len(li) > 0, len(le) > 0
+        flags[l] = int(ic) | (int(ec) << 1)
+        if ic:
+            i_min, j_min = _argmin_matrix(li, le if ec else default)
+            pi[l] = li[i_min]
+            if not ec:
+                pe[l] = external_wall[-j_min]
+        if ec:
+            i_min, j_min = _argmin_matrix(le, li if ic else default)
+            pe[l] = le[i_min]
+            if not ic:
+                pi[l] = internal_wall[-j_min]
+    return flags, pi, pe

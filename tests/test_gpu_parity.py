@@ -524,3 +524,44 @@ def test_evenly_spaced_fx_and_grid(dev):
     for f in (0, 31, 63):
         r = O.evenly_spaced_fx(xs[f], fs[f], 37)
         assert np.abs(out[f] - r).max() < 1e-5
+
+
+def test_semipolar_grid_intersection_matches_oracle(dev):
+    """intersect_semipolar_grid: the HIP kernel against the numpy restatement (same float64 operations: bit-identical),
+    plus geometric properties of the selected points.  The reference needs shapely (absent): parity unpinned."""
+    from artspeech_amd.area_function import (area_function_batched, build_semipolar_grid, intersect_semipolar_grid,
+                                             intersect_semipolar_grid_batched)
+    grid = build_semipolar_grid((0.5, 0.5), np.pi / 12, -np.pi / 12, 0.05, np.pi / 24)
+    rng = np.random.default_rng(0)
+    frames = []
+    for f in range(5):  # bent tubes around the grid centre, perturbed; the last one has a short external wall
+        ang = np.linspace(-np.pi * 0.45, np.pi * (0.95 if f < 4 else 0.4), 100)
+        wob = 1.0 + 0.05 * rng.standard_normal(100).cumsum() / 10
+        inner = np.stack([0.5 + 0.12 * wob * np.cos(ang), 0.5 - 0.12 * wob * np.sin(ang)], 1)
+        outer = np.stack([0.5 + 0.25 * np.cos(ang[: 100 if f < 4 else 60].repeat(1)), 0.5 - 0.25 * np.sin(ang[: 100 if f < 4 else 60])], 1)
+        if len(outer) < 100:
+            outer = np.concatenate([outer, np.repeat(outer[-1:], 100 - len(outer), 0) + np.linspace(0, 1e-3, 100 - len(outer))[:, None]])
+        frames.append(np.array([inner.T, outer.T]))
+    air = torch.from_numpy(np.array(frames)).to(dev)
+    flags, p_int, p_ext = intersect_semipolar_grid_batched(air, grid)
+    flags, p_int, p_ext = flags.cpu().numpy(), p_int.cpu().numpy(), p_ext.cpu().numpy()
+    for f, fr in enumerate(frames):
+        wf, wi, we = O.intersect_semipolar_grid(fr[0].T, fr[1].T, grid)
+        assert np.array_equal(flags[f], wf)
+        live = wf != 0
+        assert np.array_equal(p_int[f][live], wi[live]) and np.array_equal(p_ext[f][live], we[live])  # bit-identical
+        assert live.sum() >= 15 and (wf == 3).sum() >= 5
+        if f == 4:
+            assert (wf == 1).sum() >= 5  # external wall not crossed: its nearer END point stands in (default_compare_to branch)
+        # a crossing lies on its grid line (straight segment between the line's end points)
+        for l in np.nonzero(wf & 1)[0]:
+            a, b, p = grid[l][0], grid[l][-1], p_int[f][l]
+            ab, ap = b - a, p - a
+            assert abs(ab[0] * ap[1] - ab[1] * ap[0]) < 1e-12 and -1e-12 <= np.dot(ap, ab) <= np.dot(ab, ab) + 1e-12
+    # single-frame API = the reference's return convention (only lines with contact), feeding area_function
+    ki, ke = intersect_semipolar_grid(frames[0][0].T, frames[0][1].T, grid)
+    wf, wi, we = O.intersect_semipolar_grid(frames[0][0].T, frames[0][1].T, grid)
+    assert np.array_equal(ki, wi[wf != 0]) and np.array_equal(ke, we[wf != 0])
+    sec = torch.from_numpy(np.array([[ki.T, ke.T]])).to(dev)
+    dists, fx = area_function_batched(sec)
+    assert torch.isfinite(dists).all() and torch.isfinite(fx).all() and (fx > 0).all()

@@ -193,3 +193,25 @@ def test_pc_autoencoder_and_critical_loss_oracle_match_reference_fixtures():
     c = load_golden("pc_critical_loss")
     loss = PO.critical_loss(c["shapes"], c["ref"], c["mask"], ["TTCD", "LA"], ["lower-lip", "tongue", "upper-lip"])
     assert abs(loss - float(c["loss"])) < 1e-7
+
+
+def test_semipolar_grid_intersection_oracle_properties():
+    """intersect_semipolar_grid restatement (parity unpinned: the reference needs shapely): known answers on a square tube."""
+    # grid lines: horizontal segments x in [0, 1] at y = 0.25, 0.5, 2.0; walls: vertical polylines x = 0.3 (internal), x = 0.8 (external)
+    grid = np.array([[[x, y] for x in np.linspace(0, 1, 5)] for y in (0.25, 0.5, 2.0)])
+    internal = np.array([[0.3, y] for y in np.linspace(0, 1, 6)])
+    external = np.array([[0.8, y] for y in np.linspace(0, 0.4, 6)])       # too short for the line at y = 0.5
+    flags, pi, pe = O.intersect_semipolar_grid(internal, external, grid)
+    assert flags.tolist() == [3, 1, 0]
+    assert np.allclose(pi[0], [0.3, 0.25]) and np.allclose(pe[0], [0.8, 0.25])
+    # line 1 crosses only the internal wall: the external wall's end nearer to the crossing stands in (its last point)
+    assert np.allclose(pi[1], [0.3, 0.5]) and np.array_equal(pe[1], external[-1])
+    # a junction hit (y = 0.2 is a vertex of the internal wall) is reported once
+    grid2 = np.array([[[x, 0.2] for x in np.linspace(0, 1, 3)]])
+    assert len(O._polyline_intersections(grid2[0], internal)) == 1
+    # several crossings of a wall: the one closest to the other wall's crossing is chosen
+    zig = np.array([[0.2, 0.0], [0.4, 1.0], [0.6, 0.0], [0.7, 1.0]])       # crosses y = 0.5 at x = 0.3, 0.5, 0.65
+    line = np.array([[[x, 0.5] for x in np.linspace(0, 1, 4)]])
+    ext = np.array([[0.9, 0.0], [0.9, 1.0]])
+    flags, pi, pe = O.intersect_semipolar_grid(zig, ext, line)
+    assert flags.tolist() == [3] and np.allclose(pi[0], [0.65, 0.5]) and np.allclose(pe[0], [0.9, 0.5])
