@@ -263,7 +263,7 @@ def main():
             "loss": round(loss, 6),
             "roofline": roofline,
             "kernels_us_per_step": kernels,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(state_dict),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(state_dict),  # rank 0 at N = 1 only
         }
         print(json.dumps(result), flush=True)
     if world > 1:
