@@ -235,6 +235,23 @@ Side* side_for_current_device() {
     }
     return &sd;
 }
+// "gradients of the trunk Linear and of all heads are final" -- recorded by as_artspeech_bwd on the stream that produced
+// them, so that a data-parallel host can start their all-reduce while the GRU backward is still running.
+hipEvent_t heads_event_for_current_device() {
+    static hipEvent_t ev[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    return ev[dev];
+}
+int record_heads_done(hipStream_t s) {
+    hipEvent_t ev = heads_event_for_current_device();
+    AS_REQUIRE(ev, AS_ERR_UNSUPPORTED, "as_artspeech_bwd: no event for this device");
+    const hipError_t e = hipEventRecord(ev, s);
+    AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_bwd: hipEventRecord failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
     hipError_t e = hipEventRecord(ev, from);
     if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
@@ -248,6 +265,14 @@ int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
 }  // namespace
 
 extern "C" void as_set_overlap(int32_t on) { g_overlap = on ? 1 : 0; }
+
+extern "C" int as_artspeech_wait_head_grads(void* stream) {
+    hipEvent_t ev = heads_event_for_current_device();
+    AS_REQUIRE(ev, AS_ERR_UNSUPPORTED, "as_artspeech_wait_head_grads: no event for this device");
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+    AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_wait_head_grads: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+    return 0;
+}
 
 extern "C" int as_artspeech_layout(const as_dims* d, as_layout* out) {
     AS_TRY(check_dims(d, "as_artspeech_layout"));
@@ -391,6 +416,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st));
     if (d->simple) {
         AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st));
+        AS_TRY(record_heads_done(st));
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
         AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
         AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st, slab, G + L.lin_b, 0));
@@ -406,6 +432,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
     AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
+    AS_TRY(record_heads_done(s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
     if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));

@@ -8,6 +8,7 @@ HIP-graph capture.  The drop-in ``nn.Module`` / autograd path (models.py, metric
 same kernels and is what the parity tests use; this engine is what the benchmark and the DP trainer use.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -25,6 +26,13 @@ class TrainStep:
         self.use_dist = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                                       and torch.distributed.get_world_size() > 1)
         self.optimizer = optimizer
+        # gradient all-reduce in two pieces: trunk + heads (74 % of the parameters, final before the GRU backward
+        # recurrences start) on a communication stream beside those recurrences, the rest after them
+        # (RCCL only: gloo's asynchronous path on device tensors is pathologically slow -- rehearsals use one all-reduce)
+        self.ar_overlap = (self.use_dist and os.environ.get("ARTSPEECH_NO_AR_OVERLAP") is None
+                           and torch.distributed.get_backend(process_group) == "nccl")
+        self.head_off = int(_lib.layout(self.dims).lin_w)
+        self.comm_stream = torch.cuda.Stream(device=model.flat.device) if self.ar_overlap else None
         L = _lib.lib()
         dev = model.flat.device
         _lib.require_gpu(model.flat, "model parameters")
@@ -55,10 +63,24 @@ class TrainStep:
                                       None, st), "as_artspeech_bwd")
 
     def all_reduce(self):
-        """One RCCL all-reduce (SUM) of the flat gradient buffer: shard losses are scaled by the GLOBAL
-        valid-frame count, so the sum over ranks is the reference's full-batch gradient."""
-        if self.use_dist:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        """RCCL all-reduce (SUM) of the flat gradient buffer: shard losses are scaled by the GLOBAL valid-frame count, so the
+        sum over ranks is the reference's full-batch gradient.  With ``ar_overlap`` the tail of the buffer (trunk Linear +
+        heads) is reduced on ``comm_stream`` as soon as ``as_artspeech_bwd`` has produced it -- while the GRU backward is
+        still running on the compute streams -- and the head of the buffer after the whole backward; the caller's stream
+        continues (Adam) only after both."""
+        if not self.use_dist:
+            return
+        dist = torch.distributed
+        if not self.ar_overlap:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        _lib.check(_lib.lib().as_artspeech_wait_head_grads(self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
+        with torch.cuda.stream(self.comm_stream):
+            tail = dist.all_reduce(self.grads[self.head_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        head = dist.all_reduce(self.grads[:self.head_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        tail.wait()
+        head.wait()
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def adam(self):
         L = _lib.lib()

@@ -105,6 +105,11 @@ int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* to
  * order).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
 void as_set_overlap(int32_t on);
 
+/* Data-parallel hook: make `stream` wait until the most recent as_artspeech_bwd on the current device has finished the
+ * gradients of the trunk Linear and of all heads, i.e. the tail [layout.lin_w, layout.total) of the flat gradient buffer
+ * (74 % of the parameters) -- their all-reduce can then run while the GRU backward recurrences are still going. */
+int as_artspeech_wait_head_grads(void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Building blocks (each is also used by the composite entry points above)
  * ---------------------------------------------------------------------------------------------- */

@@ -176,3 +176,20 @@ def test_evaluation_entry_points_write_reference_outputs(dev, tmp_path):
                model_kwargs={"embed_dim": 32, "num_heads": 4, "num_layers": 1, "num_feat": 100})
     res = cli_t.main(**cfg)
     assert np.isfinite(res["loss"]) and os.path.exists(tmp_path / "tf" / "test_results.csv")
+
+
+def test_overlapped_gradient_all_reduce_equals_single_all_reduce(dev):
+    """Two ranks (gloo, sharing the GPU): the two-piece all-reduce that overlaps the GRU backward leaves bit-identical
+    parameters and keeps the ranks in sync (tools/check_dp_overlap.py exits non-zero otherwise)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, ARTSPEECH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "check_dp_overlap.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("overlap == plain all-reduce: True") == 2
