@@ -193,3 +193,8 @@ def test_overlapped_gradient_all_reduce_equals_single_all_reduce(dev):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("overlap == plain all-reduce: True") == 2
+    # transformer trainer: all-reduce hooks fired during the backward == full-batch gradients
+    cmd[-1] = os.path.join(ROOT, "tools", "check_dp_transformer.py")
+    cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and res.stdout.count("ok = True") == 2, res.stdout[-2000:] + res.stderr[-2000:]

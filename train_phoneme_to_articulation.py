@@ -131,8 +131,9 @@ def main(datadir, database_name, num_epochs, batch_size, patience, learning_rate
          valid_seq_dict, test_seq_dict, vocab_filepath, articulators, model_kwargs=None, num_workers=0, clip_tails=True,
          state_dict_filepath=None, checkpoint_filepath=None, seed=0, synthetic=None, results_dir=None):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on one GPU
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+        dist.init_process_group(backend)
     rank, world = _world()
     device = torch.device("cuda", torch.cuda.current_device())
     logging.info(f"Running on '{device}' (rank {rank}/{world})")

@@ -41,15 +41,37 @@ def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
-def _all_reduce_grads(model):
-    """One all-reduce over a flattened copy of all gradients (shard losses are scaled by the global frame count)."""
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dp.all_reduce_flat(flat)
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+class _GradientExchange:
+    """Data-parallel gradient all-reduce (SUM; shard losses are scaled by the global frame count) overlapped with the
+    backward: a post-accumulate hook on every parameter starts that tensor's all-reduce the moment autograd has finished its
+    gradient -- the parameters are stored stacked per decoder layer, so the 1.68 GB of gradients go out as ~30 large
+    collectives, last layers first, while the earlier layers are still being differentiated.  `wait()` before the optimizer."""
+
+    def __init__(self, model):
+        self.pending = []
+        self.asynchronous = dist.get_backend() == "nccl"  # gloo (CPU rehearsals): blocking calls
+        for p in model.parameters():
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=self.asynchronous)
+        if self.asynchronous:
+            self.pending.append(work)
+
+    def wait(self):
+        for work in self.pending:
+            work.wait()
+        self.pending.clear()
+
+
+_EXCHANGE = {}
+
+
+def _gradient_exchange(model):
+    if id(model) not in _EXCHANGE:
+        _EXCHANGE[id(model)] = _GradientExchange(model)
+    return _EXCHANGE[id(model)]
 
 
 def run_epoch(phase, epoch, model, dataloader, optimizer, criterion, fn_metrics=None, scheduler=None, device=None):
@@ -81,9 +103,10 @@ def run_epoch(phase, epoch, model, dataloader, optimizer, criterion, fn_metrics=
                             src_attn_mask=src_attn_mask, tgt_attn_mask=tgt_attn_mask)
             loss = masked_euclidean_loss(outputs, targets, lengths, n_valid_global=n_valid_global)
             if training:
+                exchange = _gradient_exchange(model) if world > 1 else None  # hooks registered once per model
                 loss.backward()
-                if world > 1:
-                    _all_reduce_grads(model)
+                if exchange is not None:
+                    exchange.wait()
                 optimizer.step()
                 if scheduler is not None:
                     scheduler.step()
@@ -102,8 +125,9 @@ def main(datadir, database_name, num_epochs, batch_size, patience, learning_rate
          test_seq_dict, vocab_filepath, articulators, model_kwargs=None, num_workers=0, clip_tails=True, state_dict_filepath=None,
          checkpoint_filepath=None, seed=0, synthetic=None, results_dir=None):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on one GPU
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+        dist.init_process_group(backend)
     rank, world = _world()
     device = torch.device("cuda", torch.cuda.current_device())
     results_dir = results_dir or RESULTS_DIR
