@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
 extern "C" int as_conv3x3_c32(const float* x, const float* w, const float* bias, const float* res, float* y, int32_t B,
                               int32_t T, int32_t D, void* stream) {
     AS_REQUIRE(x && w && bias && y && B > 0 && D > 0 && T > 0, AS_ERR_BAD_ARG, "as_conv3x3_c32: bad argument");
+    AS_REQUIRE((long)T * D * 32 < (1L << 31), AS_ERR_UNSUPPORTED, "as_conv3x3_c32: T * D = %ld too large for 32-bit frame offsets", (long)T * D);
     const long P = (long)B * D * T;
     const int nhp = (128 + 2 * D + 2 + 159) / 160 * 160;  // halo rows rounded up to whole staging passes (32 rows x 5)
     size_t halo_bytes = (size_t)(nhp + 1) * 33 * sizeof(float);
