@@ -12,33 +12,38 @@ constexpr int MAXC = 8;   // row length <= 64 * MAXC for the head kernels (regis
 constexpr int MAXCW = 44;  // wide rows (transformer: LayerNorm over 10*d / A*d features)
 
 // ---- x_hat = (x - mean) * rstd over the last dim (biased variance, eps) -------------------------
+// one wave per row, NW = ceil(D / 64) values per lane; branch-free clamped loads (all in flight together)
+template <int NW>
 __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restrict__ x, float* __restrict__ xhat,
                                                             float* __restrict__ rstd, long rows, int D, float eps) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + row * D;
-    float v[MAXC];
+    float v[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = xr[i < D ? i : D - 1];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int i = lane + 64 * c;
-        v[c] = i < D ? xr[i] : 0.f;
+    for (int c = 0; c < NW; ++c) {
+        if (lane + 64 * c >= D) v[c] = 0.f;
         s += v[c];
     }
     const float mean = as_wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int i = lane + 64 * c;
-        const float d = i < D ? v[c] - mean : 0.f;
+    for (int c = 0; c < NW; ++c) {
+        const float d = lane + 64 * c < D ? v[c] - mean : 0.f;
         v[c] = d;
         q += d * d;
     }
     const float rs = 1.0f / sqrtf(as_wave_sum(q) / D + eps);
     float* o = xhat + row * D;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NW; ++c) {
         const int i = lane + 64 * c;
         if (i < D) o[i] = v[c] * rs;
     }
@@ -57,13 +62,20 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
     if (row >= rows) return;
     const float* dyr = dy + row * D;
     const float* xr = xhat + row * D;
-    float g[MW], h[MW];
+    const float* rr = relu_src ? relu_src + row * D : xr;  // no mask: any finite source, the select below ignores it
+    float g[MW], h[MW], m[MW];
+#pragma unroll
+    for (int c = 0; c < MW; ++c) {  // branch-free clamped loads: everything in flight together
+        const int i = lane + 64 * c;
+        const int ic = i < D ? i : D - 1;
+        g[c] = dyr[ic];
+        h[c] = xr[ic];
+        m[c] = rr[ic];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MW; ++c) {
-        const int i = lane + 64 * c;
-        g[c] = i < D ? dyr[i] : 0.f;
-        h[c] = i < D ? xr[i] : 0.f;
+        if (lane + 64 * c >= D) g[c] = 0.f;
         s1 += g[c];
         s2 += g[c] * h[c];
     }
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
         const int i = lane + 64 * c;
         if (i < D) {
             float v = rs * (g[c] - m1 - h[c] * m2);
-            if (relu_src && !(relu_src[row * D + i] > 0.f)) v = 0.f;
+            if (relu_src && !(m[c] > 0.f)) v = 0.f;
             o[i] = v;
         }
     }
@@ -488,17 +500,25 @@ inline int ew_grid(long n) {
 
 int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXC, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXC);
-    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, x, xhat, rstd, rows, D, 1e-5f);
+#define AS_NORM_FWD(NW) hipLaunchKernelGGL(normalize_fwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, x, xhat, rstd, rows, D, 1e-5f)
+    if (D <= 64) AS_NORM_FWD(1);
+    else if (D <= 128) AS_NORM_FWD(2);
+    else if (D <= 256) AS_NORM_FWD(4);
+    else AS_NORM_FWD(MAXC);
+#undef AS_NORM_FWD
     AS_LAUNCH_CHECK("normalize_fwd");
     return 0;
 }
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
                      int D, hipStream_t st) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXCW, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXCW);
-    if (D <= 64 * MAXC)
-        hipLaunchKernelGGL(normalize_bwd_kernel<MAXC>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
-    else
-        hipLaunchKernelGGL(normalize_bwd_kernel<MAXCW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D);
+#define AS_NORM_BWD(MW) \
+    hipLaunchKernelGGL(normalize_bwd_kernel<MW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D)
+    if (D <= 128) AS_NORM_BWD(2);
+    else if (D <= 256) AS_NORM_BWD(4);
+    else if (D <= 64 * MAXC) AS_NORM_BWD(MAXC);
+    else AS_NORM_BWD(MAXCW);
+#undef AS_NORM_BWD
     AS_LAUNCH_CHECK("normalize_bwd");
     return 0;
 }
