@@ -122,11 +122,12 @@ int gemm_nt(const float* A, long lda, const float* Bw, long ldb, float* C, long 
 }
 // C[M][N] = A[M][K] . B[K][N]   (input gradient: reduction over the rows of B)
 int gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
-            int batch = 1, long ab = 0, long bb = 0, long cb = 0) {
+            int batch = 1, long ab = 0, long bb = 0, long cb = 0, float* slab = nullptr) {
     as_gemm g{};
     g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
     g.a_i = lda; g.a_k = 1; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
     g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb;
+    g.splitk_ws = slab; g.splitk_ws_floats = slab ? SLAB_FLOATS : 0;  // few output tiles + long reduction: split K
     return as_gemm_f32(&g, st);
 }
 // C[M][N] = A[K][M]^T . B[K][N]   (weight gradient: reduction over the rows of both)
@@ -188,7 +189,8 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
     AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
     AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
-    AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st));
+    // N = H columns only (100 x 2 tiles of 64 x 64) under a 2816-long reduction: split K over the main-stream slab
+    AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st, 1, 0, 0, 0, ws + w.slab));
     AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));
     return 0;
 }
@@ -433,7 +435,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_TRY(record_heads_done(s2));  // [lin_w, total) of the flat gradient buffer is final from here on
-    AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st));
+    AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
     if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence

@@ -587,7 +587,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     if (force && !strcmp(force, "128x128")) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "64x128")) return launch<64, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "128x64")) return launch<128, 64>(k, g->batch, a_kc, b_kc, st);
-    if (!force && big >= 256 && g->N >= 128) {
+    if (!force && big >= 512 && g->N >= 128) {  // fewer 128x128 tiles leave most of the 768 resident slots empty: 64x64 then
+                                                 // (measured 6400 x 768 x 256: 300 tiles 39.9 us, as 1200 64x64 tiles 30.1 us)
         // 128x128 tiles that do not fill the resident slots (3 per CU) with a long reduction: split K so that the persistent
         // workgroups get equal shares (measured: 440 tiles, K = 6400 run at 75 TF/s, 768 tiles of the same shape at 100)
         static const int slots = resident_blocks(gemm_f32_kernel<128, 128, true, true, true>);

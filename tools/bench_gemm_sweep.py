@@ -37,5 +37,5 @@ def run(M, N, K, batch=1, iters=10):
 
 
 for shape in [(8192, 8192, 8192, 1), (4096, 4096, 4096, 1), (8192, 8192, 256, 1), (6400, 256, 256, 11), (6400, 256, 256, 12), (6144, 256, 256, 16),
-              (6400, 256, 4096, 11), (6400, 2816, 128, 1), (6400, 2816, 256, 1), (70400, 256, 256, 1)]:
+              (6400, 256, 4096, 11), (6400, 2816, 128, 1), (6400, 2816, 256, 1), (70400, 256, 256, 1), (6400, 768, 256, 1), (6400, 128, 256, 1)]:
     run(*shape)
