@@ -60,13 +60,29 @@ class Adapter(_Params):
                                      nn.LayerNorm(out_features), nn.Linear(out_features, out_features))
 
 
-def _gemm(A, W, bias, out, act=0):
-    """out[M][N] = act(A[M][K] . W[N][K]^T + bias)."""
+_SLAB = {}
+
+
+def _slab(dev):
+    if dev not in _SLAB:
+        _SLAB[dev] = torch.empty(4 << 20, dtype=torch.float32, device=dev)  # split-K partial tiles (16 MB)
+    return _SLAB[dev]
+
+
+def _gemm(A, W, bias, out, act=0, split_k=False):
+    """out[M][N] = act(A[M][K] . W[N][K]^T + bias).  split_k (act == 0 only): few output tiles under a long reduction --
+    the bias is laid down first and the GEMM accumulates onto it, its K range split over workgroups (deterministic slabs)."""
     g = _lib.Gemm()
-    g.A, g.B, g.C, g.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr()
+    g.A, g.B, g.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
     g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
     g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = g.K, 1, g.K, 1, g.N
     g.batch, g.act = 1, act
+    if split_k and act == 0:
+        out.copy_(bias.expand_as(out))
+        slab = _slab(out.device)
+        g.accumulate, g.splitk_ws, g.splitk_ws_floats = 1, slab.data_ptr(), slab.numel()
+    else:
+        g.bias = bias.data_ptr()
     _lib.check(_lib.lib().as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
     return out
 
@@ -172,7 +188,8 @@ class DeepSpeech2(nn.Module):
                 _lib.check(L.as_conv3x3_c32(_lib.ptr(act), _lib.ptr(w2), _lib.ptr(r.cnn2.bias), _lib.ptr(fmap), _lib.ptr(nxt), B, T, D, st),
                            "as_conv3x3_c32")
                 fmap = nxt
-            h = _gemm(fmap.view(B * T, D * OUT_CHANNELS), w["linear"], self.linear.bias, torch.empty(B * T, H, device=dev, dtype=f32))
+            h = _gemm(fmap.view(B * T, D * OUT_CHANNELS), w["linear"], self.linear.bias, torch.empty(B * T, H, device=dev, dtype=f32),
+                      split_k=True)  # K = 32 * D (2560) against N = H (64) columns
             lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
             gi = torch.empty(B * T, 3 * H, device=dev, dtype=f32)
             for blk in self.recurrent_layers:
