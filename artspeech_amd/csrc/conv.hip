@@ -267,8 +267,10 @@ __global__ __launch_bounds__(256) void ln_feat_gelu_kernel(const float* __restri
     float v[MAXD];
     float s = 0.f;
 #pragma unroll
+    for (int d = 0; d < MAXD; ++d) v[d] = xp[(long)(d < D ? d : D - 1) * Cc];  // branch-free: all loads in flight together
+#pragma unroll
     for (int d = 0; d < MAXD; ++d) {
-        v[d] = d < D ? xp[(long)d * Cc] : 0.f;
+        if (d >= D) v[d] = 0.f;
         s += v[d];
     }
     const float mean = s / D;
