@@ -134,11 +134,11 @@ int gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long 
 // colsum (optional): column sums of A, i.e. the bias gradient that goes with this weight gradient, [batch][M]
 int gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
             float* slab, float* colsum = nullptr, long csb = 0, int batch = 1, long ab = 0, long bb = 0, long cb = 0,
-            int kshift = 0, int kT = 0) {
+            int kshift = 0, int kT = 0, int kshift_batch = 0) {
     as_gemm g{};
     g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
     g.a_i = 1; g.a_k = lda; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
-    g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.b_kshift = kshift; g.b_kT = kT;
+    g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.b_kshift = kshift; g.b_kT = kT; g.b_kshift_batch = kshift_batch;
     g.splitk_ws = slab; g.splitk_ws_floats = SLAB_FLOATS; g.colsum = colsum; g.colsum_batch = csb;
     return as_gemm_f32(&g, st);
 }
@@ -442,18 +442,17 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
     AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
     AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
-    for (int dir = 0; dir < 2; ++dir)  // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame
-        AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh1 + dir * 3 * H, 6 * H, ws + w.y1 + dir * H, 2 * H, G + L.w_hh[1] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, s2, sl2, G + L.b_hh[1] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
+    // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame; both directions as one batch of two
+    AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh1, 6 * H, ws + w.y1, 2 * H, G + L.w_hh[1], H, 3 * H, H, R, s2, sl2, G + L.b_hh[1], 3 * H, 2,
+                   3 * H, H, 3L * H * H, -1, T, 2));
     // ---- layer-0 gradients: hidden-to-hidden on the side stream, embedding / input projection here
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[2]));
-    for (int dir = 0; dir < 2; ++dir)
-        AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh0 + dir * 3 * H, 6 * H, ws + w.y0 + dir * H, 2 * H, G + L.w_hh[0] + (long)dir * 3 * H * H, H,
-                       3 * H, H, R, s2, sl2, G + L.b_hh[0] + dir * 3 * H, 0, 1, 0, 0, 0, dir ? 1 : -1, T));
+    AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s2, sl2, G + L.b_hh[0], 3 * H, 2,
+                   3 * H, H, 3L * H * H, -1, T, 2));
     // embedding + layer-0 input projection through the token table
     AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
     AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
-    AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st));
+    AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st, 1, 0, 0, 0, slab));
     if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side stream's work
     return 0;
 }

@@ -9,6 +9,8 @@
 // (loads of tile t+1 in flight while the matrix core works on tile t), one barrier per K tile.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "as_common.h"
 
@@ -23,17 +25,25 @@ struct GemmK {
     int M, N, K;
     long a_i, a_k, b_j, b_k, ldc;
     long a_batch, b_batch, c_batch, bias_batch;
-    int act, accumulate, b_kshift, b_kT;
+    int act, accumulate, b_kshift, b_kT, b_kshift_batch;
     int a_vec, b_vec;
     // split-K: blockIdx.y owns reduction range [y*kchunk, (y+1)*kchunk); partial tiles go to a dense slab
     // [split][batch][M][N + has_colsum]; a second kernel sums the slabs in a fixed order (deterministic).
     int splitk, kchunk, batch;
     float* slab;
+    // optional arrival counters, one per (batch, output tile), zero between launches: the workgroup that delivers the last
+    // partial of a tile sums the slabs itself (fixed k order) and runs the ordinary epilogue -- no second kernel
+    int* counters;
     // optional fused column sum of the (output-contiguous) A operand: colsum[i] = sum_k Aop[i][k]
     float* colsum; long colsum_batch;
     // grouped batches: per-batch element offsets (device arrays) override the linear batch strides
     const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
 };
+
+// device-scope accesses for data handed between workgroups of one launch (they may sit on different XCDs, whose L2s are not
+// coherent with each other for ordinary accesses)
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int BI, bool KC> struct Img { static constexpr int size = KC ? BI * (BK + 1) : BK * BI; };
 
@@ -156,6 +166,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
     // other workgroups' MFMAs fill this one's barrier / prologue / epilogue bubbles).
     __shared__ __attribute__((aligned(16))) float sA[1][Img<BM, A_KC>::size];
     __shared__ __attribute__((aligned(16))) float sB[1][Img<BN, B_KC>::size];
+    __shared__ int s_last;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
     const long total = per_batch * g.batch;
     struct Work {
         const float* A; const float* B; float* C;
-        int m0, n0, bz, ks, kbeg, kend, tn_idx;
+        int m0, n0, bz, ks, kbeg, kend, tn_idx, kshift, xy;
     };
     auto decode = [&](long w) {
         Work x;
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         const int wrem = (int)(w - x.bz * per_batch);
         x.ks = wrem / per_split;
         const int xy = wrem - x.ks * per_split;
+        x.xy = xy;
         x.tn_idx = xy / tiles_m;
         x.m0 = (xy - x.tn_idx * tiles_m) * BM;
         x.n0 = x.tn_idx * BN;
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         x.C = g.C + (g.c_off ? g.c_off[x.bz] : (long)x.bz * g.c_batch);
         x.kbeg = x.ks * g.kchunk;
         x.kend = min(g.K, x.kbeg + g.kchunk);
+        x.kshift = g.b_kshift + x.bz * g.b_kshift_batch;
         return x;
     };
     long work = blockIdx.x;
@@ -193,12 +206,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
     Work w = decode(work);
     float4 ra[BM / 32], rb[BN / 32];
     tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
-    tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+    tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, w.kshift, g.b_kT, tid);
     for (;;) {
         const float* A = w.A;
         const float* B = w.B;
         float* C = w.C;
-        const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend;
+        const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend, kshift = w.kshift;
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) {
                 tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
-                tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+                tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, kshift, g.b_kT, tid);
             }
             const float* a_s = sA[0];
             const float* b_s = sB[0];
@@ -249,19 +262,23 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         // the next tile's first operand tiles go in flight ahead of this tile's stores
         work += gridDim.x;
         const bool more = work < total;
-        const int ks = w.ks;
+        const int ks = w.ks, xy = w.xy;
         if (more) {
             w = decode(work);
             tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
-            tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, g.b_kshift, g.b_kT, tid);
+            tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, w.kshift, g.b_kT, tid);
         }
 
         // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const bool whole = m0 + BM <= g.M;  // workgroup-uniform: whole rows, only a per-lane column predicate
+        bool final_store = true;
+        // 64x64 tiles only: in the larger tiles the summing loop costs the main loop its registers (scratch spills)
+        const bool fix = BM * BN <= 64 * 64 && g.counters != nullptr;
         if (g.splitk > 1) {
             const int ncs = g.colsum ? 1 : 0;
             const long W = g.N + ncs;
-            float* slab = g.slab + ((long)ks * g.batch + bz) * (long)g.M * W;
+            const long slab_k = (long)g.batch * g.M * W;  // one split's slab
+            float* slab = g.slab + (long)ks * slab_k + (long)bz * g.M * W;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * WN + j * 32 + l31;
@@ -271,11 +288,59 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < g.M) slab[(long)row * W + col] = acc[i][j][r];
+                        if (row < g.M) {
+                            if (fix) st_agent(&slab[(long)row * W + col], acc[i][j][r]);
+                            else slab[(long)row * W + col] = acc[i][j][r];
+                        }
                     }
             }
-            if (do_cs && m0 + tid < g.M) slab[(long)(m0 + tid) * W + g.N] = cs_acc;
-        } else {
+            if (do_cs && m0 + tid < g.M) {
+                if (fix) st_agent(&slab[(long)(m0 + tid) * W + g.N], cs_acc);
+                else slab[(long)(m0 + tid) * W + g.N] = cs_acc;
+            }
+            final_store = false;
+            if (fix) {
+                // The partial went out as agent-scope (write-through) stores and is read back by agent-scope loads, which do
+                // not hit in another XCD's L2; waiting for the stores' acknowledgement orders them before the arrival count.
+                // A __threadfence() here would write back the whole L2 per workgroup: measured 2.4 vs 1.45 ms per step.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {   // ... before its arrival is counted
+                    int* cnt = g.counters + (long)bz * per_split + xy;
+                    const int last = atomicAdd(cnt, 1) == g.splitk - 1;
+                    // every partial of the tile has arrived: nobody touches the counter again this launch
+                    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_last = last;
+                }
+                __syncthreads();
+                if (s_last) {
+                    const float* sl = g.slab + (long)bz * g.M * W;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    cs_acc = 0.f;
+                    for (int kk = 0; kk < g.splitk; ++kk, sl += slab_k) {  // k = 0, 1, ...: the order of splitk_reduce_kernel
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int col = min(n0 + wn * WN + j * 32 + l31, g.N - 1);
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                                    acc[i][j][r] += ld_agent(&sl[(long)row * W + col]);
+                                }
+                        }
+                        if (do_cs) cs_acc += ld_agent(&sl[(long)min(m0 + tid, g.M - 1) * W + g.N]);
+                    }
+                    final_store = true;
+                }
+            }
+        }
+        if (final_store) {
             if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
             const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
             if (whole && !g.accumulate) {
@@ -494,6 +559,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK g) {
     }
 }
 
+// Same sum for MANY slabs over FEW outputs (dW_hh: 50 slabs of 49 536 floats): a thread per output would walk the slabs
+// alone.  Four quarter-workgroups each take every 4th slab of 64 consecutive outputs and the partials meet in LDS in a fixed
+// order (deterministic).  The k order differs from splitk_reduce_kernel's, so one shape always takes the same kernel.
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmK g) {
+    __shared__ float part[3][64];
+    const int ncs = g.colsum ? 1 : 0;
+    const long W = g.N + ncs;
+    const long per = (long)g.M * W;
+    const long total = (long)g.batch * per;
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * 64 + i;
+    const long src = idx < total ? idx : total - 1;
+    float s = 0.f;
+    for (int k = q; k < g.splitk; k += 4) s += g.slab[(long)k * total + src];
+    if (q > 0) part[q - 1][i] = s;
+    __syncthreads();
+    if (q > 0 || idx >= total) return;
+    s = ((s + part[0][i]) + part[1][i]) + part[2][i];
+    const long bz = idx / per, rem = idx - bz * per;
+    const long row = rem / W;
+    const int col = (int)(rem - row * W);
+    if (col < g.N) {
+        float* c = g.C + bz * g.c_batch + row * g.ldc + col;
+        *c = g.accumulate ? *c + s : s;
+    } else {
+        g.colsum[bz * g.colsum_batch + row] = s;
+    }
+}
+
 // resident workgroups of one kernel instance on the whole device (queried once per instance)
 template <typename Kern>
 int resident_blocks(Kern kern) {
@@ -502,6 +596,28 @@ int resident_blocks(Kern kern) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         cus = 256;
     return per_cu * cus;
+}
+
+// Arrival counters for the in-kernel split-K reduction: one zeroed array per (device, stream), created on first use (like
+// the side stream: never inside a stream capture) and left zero by every launch.  nullptr = fall back to the reduce kernel.
+constexpr int COUNTERS = 8192;
+int* counters_for(hipStream_t st) {
+    struct Slot { int dev; hipStream_t st; int* p; };
+    static std::mutex mu;
+    static std::vector<Slot> slots;
+    static const bool off = getenv("AS_GEMM_NO_FIXUP") != nullptr;  // ablation: always the separate reduce kernel
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Slot& s : slots)
+        if (s.dev == dev && s.st == st) return s.p;
+    if (slots.size() >= 64) return nullptr;
+    int* p = nullptr;
+    if (hipMalloc(&p, COUNTERS * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, COUNTERS * sizeof(int), st) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    slots.push_back({dev, st, p});
+    return p;
 }
 
 template <int BM, int BN>
@@ -552,12 +668,12 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.M = g->M; k.N = g->N; k.K = g->K;
     k.a_i = g->a_i; k.a_k = g->a_k; k.b_j = g->b_j; k.b_k = g->b_k; k.ldc = g->ldc;
     k.a_batch = g->a_batch; k.b_batch = g->b_batch; k.c_batch = g->c_batch; k.bias_batch = g->bias_batch;
-    k.act = g->act; k.accumulate = g->accumulate; k.b_kshift = g->b_kshift; k.b_kT = g->b_kT;
+    k.act = g->act; k.accumulate = g->accumulate; k.b_kshift = g->b_kshift; k.b_kT = g->b_kT; k.b_kshift_batch = g->b_kshift_batch;
     const long a_ld = a_kc ? g->a_i : g->a_k, b_ld = b_kc ? g->b_j : g->b_k;
     k.a_vec = aligned16(g->A) && a_ld % 4 == 0 && g->a_batch % 4 == 0;
     k.b_vec = aligned16(g->B) && b_ld % 4 == 0 && g->b_batch % 4 == 0;
     hipStream_t st = (hipStream_t)stream;
-    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr;
+    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr; k.counters = nullptr;
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
     k.bias_off = (const long*)g->bias_off;
@@ -619,7 +735,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     const long tiles = (long)as_cdiv(g->M, 64) * as_cdiv(g->N, 64) * g->batch;
     if (g->splitk_ws && !grouped && tiles < 512 && g->K >= 512 && !g->bias && g->act == 0) {
         long sk = (1024 + tiles - 1) / tiles;
-        if (sk > g->K / 128) sk = g->K / 128;
+        const int min_chunk = tiles * (g->K / 128) < 128 ? 64 : 128;  // a handful of tiles: shorter chunks, still >= 2 k-steps
+        if (sk > g->K / min_chunk) sk = g->K / min_chunk;
         if (sk > 64) sk = 64;
         const long per = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
         if (sk * per > g->splitk_ws_floats) sk = g->splitk_ws_floats / per;
@@ -627,14 +744,22 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
             k.kchunk = (int)as_round_up(as_cdiv(g->K, sk), BK);
             k.splitk = as_cdiv(g->K, k.kchunk);
             k.slab = g->splitk_ws;
+            // few slabs: the last workgroup to arrive at a tile sums them in the kernel (input gradient of GRU layer 1, 3 slabs:
+            // 52 us against 36 + 45 for a reduce kernel that has to squeeze in beside the side stream's persistent GEMM).
+            // Many slabs (a handful of tiles) would leave the sums to a handful of workgroups: the wide reduce kernel then.
+            if (k.splitk <= 16 && tiles <= COUNTERS) k.counters = counters_for(st);
         }
     }
     AS_TRY((launch<64, 64>(k, g->batch, a_kc, b_kc, st)));
-    if (k.splitk > 1) {
+    if (k.splitk > 1 && !k.counters) {
         const long total = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
-        long blocks = (total + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, k);
+        if (k.splitk >= 16 && total <= (1L << 20)) {
+            hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, k);
+        } else {
+            long blocks = (total + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, k);
+        }
         AS_LAUNCH_CHECK("as_gemm_f32(splitk reduce)");
     }
     return 0;

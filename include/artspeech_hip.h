@@ -150,7 +150,8 @@ int as_lstm_bidir_bwd(const float* dy, const float* gates, const float* w_hh, co
  * Aop[i][k] = A[i*a_i + k*a_k] and Bop[j][k] = B[j*b_j + k*b_k]; one stride of each pair must be 1.
  * act: 0 none, 1 ReLU, 2 sigmoid, 3 exact (erf) GELU.  accumulate != 0 adds to C.  b_kshift/b_kT: if b_kT > 0 the B operand's
  * reduction index k is read at k + b_kshift and is zero unless 0 <= (k % b_kT) + b_kshift < b_kT
- * (the h_{t-1} operand of dW_hh). */
+ * (the h_{t-1} operand of dW_hh); batch g uses the shift b_kshift + g * b_kshift_batch (forward and reverse direction
+ * of a bidirectional layer in one batched call: -1 and +1). */
 typedef struct as_gemm {
     const float* A; const float* B; float* C; const float* bias;
     int32_t M, N, K;
@@ -172,6 +173,7 @@ typedef struct as_gemm {
        the bf16 MFMA with every fp32 element split on the fly into 2 / 3 bf16 pieces and the product rebuilt from 3 / 6
        cross terms with fp32 accumulation (error ~2^-16 / ~2^-23 of sum |a||b|); other shapes silently stay exact. */
     int32_t precision;
+    int32_t b_kshift_batch;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 
