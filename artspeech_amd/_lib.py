@@ -30,7 +30,7 @@ class Layout(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64)]
+    _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64), ("dout_presigmoid", C.c_int32)]
 
 
 class Gemm(C.Structure):
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "as_euclid_bwd": (_I32, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "as_euclid_masked_partials": (_I32, []),
     "as_euclid_masked_fwd_bwd": (_I32, [_P, _P, _I64, _P, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P]),
+    "as_euclid_masked_fwd_bwd_presigmoid": (_I32, [_P, _P, _I64, _P, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P]),
     "as_p2cp_fwd": (_I32, [_P, _I64, _I64, _I64, _I32, _P, _I64, _I64, _I64, _I32, _I64, _P, _P]),
     "as_p2cp_utterance_mean": (_I32, [_P, _P, _I32, _I32, _I32, _F, _P, _P]),
     "as_tract_variables_fwd": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),

@@ -177,15 +177,17 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
 //  head_bwd_dx : the input-gradient chain (critical path towards the GRU backward)
 //  head_bwd_dw : weight/bias gradients + LayerNorm-affine unfold (only consumes what the chain left in ws)
 // relu_src: optional [rows][H] activation whose ReLU produced x (its mask is fused into the last step)
+// presig: dout already is the gradient w.r.t. the pre-sigmoid activations (as_opts.dout_presigmoid): read in place
 int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const float* out, const float* dout, int64_t rows,
-                float* dx, const float* relu_src, float* ws, hipStream_t st) {
+                float* dx, const float* relu_src, float* ws, hipStream_t st, bool presig = false) {
     (void)L; (void)P;
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
-    AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
-    AS_STEP("headb.dx3", st, gemm_nn(ws + w.dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
+    const float* dpre3 = presig ? dout : ws + w.dpre3;
+    if (!presig) AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
+    AS_STEP("headb.dx3", st, gemm_nn(dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
     AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
     AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
     AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
@@ -196,13 +198,14 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
 }
 
 int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* G, float* ws, float* slab,
-                hipStream_t st) {
+                hipStream_t st, const float* dpre3_in = nullptr) {
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
     // each weight-gradient GEMM also emits the bias gradient = column sums of its A operand
-    AS_STEP("headb.dw3", st, gemm_tn(ws + w.dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
+    const float* dpre3 = dpre3_in ? dpre3_in : ws + w.dpre3;
+    AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
     AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D));
     AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0));
     // unfold the LayerNorm affines
@@ -415,9 +418,11 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     float* dzlin = ws + w.head + hw.dxhat;  // reused: d(trunk pre-activation) [R][H]
     float* hws = ws + w.head;
     // heads: input-gradient chain (+ the trunk ReLU mask fused into the last normalize-backward)
-    AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st));
+    const bool presig = opts && opts->dout_presigmoid;
+    const float* dpre3 = presig ? dout : nullptr;
+    AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st, presig));
     if (d->simple) {
-        AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st));
+        AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st, dpre3));
         AS_TRY(record_heads_done(st));
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
         AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
@@ -432,7 +437,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
-    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2));
+    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_TRY(record_heads_done(s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void euclid_bwd_kernel(const float* __restrict
 // ---------------------------------------------------------------- fused masked mean + gradient
 constexpr int LOSS_BLOCKS = 1024;
 
+template <bool PRESIG>
 __global__ __launch_bounds__(256) void euclid_masked_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                             long tgt_T, const int* __restrict__ lengths, int T, int A,
                                                             int N, long points, float scale, float* __restrict__ dout,
@@ -54,13 +55,15 @@ __global__ __launch_bounds__(256) void euclid_masked_kernel(const float* __restr
         const long ob = (frame * A + a) * 2 * N + n;
         if (t < lengths[b]) {
             const long tb = ((b * tgt_T + t) * A + a) * 2 * N + n;
-            const float dx = out[ob] - tgt[tb], dy = out[ob + N] - tgt[tb + N];
+            const float ox = out[ob], oy = out[ob + N];
+            const float dx = ox - tgt[tb], dy = oy - tgt[tb + N];
             const float d = sqrtf(dx * dx + dy * dy);
             s += d;
             if (dout) {
                 const float g = scale / d;
-                dout[ob] = dx * g;
-                dout[ob + N] = dy * g;
+                // PRESIG: through the model's final sigmoid as well (same product order as sigmoid_bwd_kernel)
+                dout[ob] = PRESIG ? dx * g * ox * (1.f - ox) : dx * g;
+                dout[ob + N] = PRESIG ? dy * g * oy * (1.f - oy) : dy * g;
             }
         } else if (dout) {
             dout[ob] = 0.f;
@@ -428,22 +431,39 @@ extern "C" int as_euclid_bwd(const float* out, const float* tgt, const float* dd
 
 extern "C" int32_t as_euclid_masked_partials(void) { return LOSS_BLOCKS; }
 
-extern "C" int as_euclid_masked_fwd_bwd(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
-                                        int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
-                                        float* partial, void* stream) {
-    AS_REQUIRE(out && tgt && lengths && loss && partial, AS_ERR_BAD_ARG, "as_euclid_masked_fwd_bwd: null pointer");
-    AS_REQUIRE(B > 0 && T > 0 && A > 0 && N > 0 && tgt_T >= T, AS_ERR_BAD_ARG,
-               "as_euclid_masked_fwd_bwd: B=%d T=%d A=%d N=%d tgt_T=%ld", B, T, A, N, (long)tgt_T);
+namespace {
+template <bool PRESIG>
+int euclid_masked_launch(const char* who, const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B, int32_t T,
+                         int32_t A, int32_t N, float scale, float* loss, float* dout, float* partial, void* stream) {
+    AS_REQUIRE(out && tgt && lengths && loss && partial, AS_ERR_BAD_ARG, "%s: null pointer", who);
+    AS_REQUIRE(B > 0 && T > 0 && A > 0 && N > 0 && tgt_T >= T, AS_ERR_BAD_ARG, "%s: B=%d T=%d A=%d N=%d tgt_T=%ld", who, B, T, A, N,
+               (long)tgt_T);
     const long points = (long)B * T * A * N;
     int blocks = ew_grid(points);
     if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(euclid_masked_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, (long)tgt_T, lengths, T, A, N, points,
+    hipLaunchKernelGGL(euclid_masked_kernel<PRESIG>, dim3(blocks), dim3(256), 0, st, out, tgt, (long)tgt_T, lengths, T, A, N, points,
                        scale, dout, partial);
-    AS_LAUNCH_CHECK("as_euclid_masked_fwd_bwd");
+    AS_LAUNCH_CHECK(who);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, scale, loss);
-    AS_LAUNCH_CHECK("as_euclid_masked_fwd_bwd(final)");
+    AS_LAUNCH_CHECK(who);
     return 0;
+}
+}  // namespace
+
+extern "C" int as_euclid_masked_fwd_bwd(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
+                                        int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
+                                        float* partial, void* stream) {
+    return euclid_masked_launch<false>("as_euclid_masked_fwd_bwd", out, tgt, tgt_T, lengths, B, T, A, N, scale, loss, dout, partial,
+                                       stream);
+}
+
+extern "C" int as_euclid_masked_fwd_bwd_presigmoid(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths,
+                                                   int32_t B, int32_t T, int32_t A, int32_t N, float scale, float* loss,
+                                                   float* dout, float* partial, void* stream) {
+    AS_REQUIRE(dout, AS_ERR_BAD_ARG, "as_euclid_masked_fwd_bwd_presigmoid: dout is required");
+    return euclid_masked_launch<true>("as_euclid_masked_fwd_bwd_presigmoid", out, tgt, tgt_T, lengths, B, T, A, N, scale, loss, dout,
+                                      partial, stream);
 }
 
 extern "C" int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t u_xy, int32_t n_u, const float* v,

@@ -46,6 +46,7 @@ class TrainStep:
         self.exp_avg = torch.zeros_like(self.grads)
         self.exp_avg_sq = torch.zeros_like(self.grads)
         self.steps = 0
+        self.bwd_opts = _lib.Opts(0.0, 0, 1)
 
     def forward_backward(self, tokens, lengths_dev, targets, loss_scale):
         """tokens (B, >=T) int64, lengths_dev (B,) int32 on device, targets (B, >=T, A, 2, N).
@@ -55,12 +56,14 @@ class TrainStep:
         B, T = self.B, self.T
         _lib.check(L.as_artspeech_fwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, None, st), "as_artspeech_fwd")
-        _lib.check(L.as_euclid_masked_fwd_bwd(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1], _lib.ptr(lengths_dev),
-                                              B, T, d.n_art, d.n_samp, float(loss_scale), _lib.ptr(self.loss),
-                                              _lib.ptr(self.dout), _lib.ptr(self.partial), st), "as_euclid_masked_fwd_bwd")
+        # criterion backward and the model's final sigmoid backward in one pass: dout holds d(loss)/d(pre-sigmoid)
+        _lib.check(L.as_euclid_masked_fwd_bwd_presigmoid(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1],
+                                                         _lib.ptr(lengths_dev), B, T, d.n_art, d.n_samp, float(loss_scale),
+                                                         _lib.ptr(self.loss), _lib.ptr(self.dout), _lib.ptr(self.partial), st),
+                   "as_euclid_masked_fwd_bwd_presigmoid")
         _lib.check(L.as_artspeech_bwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.dout), _lib.ptr(self.grads), _lib.ptr(self.ws),
-                                      None, st), "as_artspeech_bwd")
+                                      C.byref(self.bwd_opts), st), "as_artspeech_bwd")
 
     def all_reduce(self):
         """RCCL all-reduce (SUM) of the flat gradient buffer: shard losses are scaled by the GLOBAL valid-frame count, so the

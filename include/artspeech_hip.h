@@ -81,6 +81,9 @@ int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T)
 typedef struct as_opts {
     float gru_dropout;      /* 0 <= p < 1 */
     uint64_t dropout_seed;
+    /* as_artspeech_bwd only: non-zero => `dout` already holds the gradient w.r.t. the PRE-sigmoid activations (written by
+       as_euclid_masked_fwd_bwd_presigmoid), so the separate dout * out * (1 - out) pass over the contours is skipped. */
+    int32_t dout_presigmoid;
 } as_opts;
 
 /* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96).
@@ -202,6 +205,11 @@ int as_euclid_bwd(const float* out, const float* tgt, const float* ddist, int64_
  * partial: workspace of as_euclid_masked_partials() floats; dout may be NULL (evaluation). */
 int32_t as_euclid_masked_partials(void);
 int as_euclid_masked_fwd_bwd(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
+                             int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
+                             float* partial, void* stream);
+/* Same, but `dout` receives d(loss)/d(pre-sigmoid activation) = dout * out * (1 - out): the criterion's backward and the
+ * model's final sigmoid backward (models.py:145) in one pass over the contours; pair with as_opts.dout_presigmoid. */
+int as_euclid_masked_fwd_bwd_presigmoid(const float* out, const float* tgt, int64_t tgt_T, const int32_t* lengths, int32_t B,
                              int32_t T, int32_t A, int32_t N, float scale, float* loss, float* dout,
                              float* partial, void* stream);
 
