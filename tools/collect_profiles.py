@@ -15,12 +15,18 @@ tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+
+
+def newest(pattern):  # gpurun_out/ accumulates the outputs of earlier calls: take the latest one
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(os.path.join(stats_dir, "*", "*_kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 
 def per_kernel(d, counter):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
+    for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
