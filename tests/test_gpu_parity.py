@@ -61,7 +61,7 @@ def test_bad_arguments_are_reported(dev):
 
 # ------------------------------------------------------------------------------------------- GEMM
 def run_gemm(dev, A, B, M, N, K, a_i, a_k, b_j, b_k, bias=None, act=0, batch=1, ab=0, bb=0, cb=0, biasb=0, ldc=None,
-             accumulate=0, C0=None, kshift=0, kT=0, precision=0):
+             accumulate=0, C0=None, kshift=0, kT=0, precision=0, kshift_batch=0, splitk_ws=None, colsum=None, colsum_batch=0):
     from artspeech_amd import _lib
     L = _lib.lib()
     ldc = ldc or N
@@ -73,6 +73,11 @@ def run_gemm(dev, A, B, M, N, K, a_i, a_k, b_j, b_k, bias=None, act=0, batch=1, 
     g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = a_i, a_k, b_j, b_k, ldc
     g.batch, g.a_batch, g.b_batch, g.c_batch, g.bias_batch = batch, ab, bb, cb, biasb
     g.act, g.accumulate, g.b_kshift, g.b_kT, g.precision = act, accumulate, kshift, kT, precision
+    g.b_kshift_batch = kshift_batch
+    if splitk_ws is not None:
+        g.splitk_ws, g.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
+    if colsum is not None:
+        g.colsum, g.colsum_batch = colsum.data_ptr(), colsum_batch
     _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
     torch.cuda.synchronize()
     return Cbuf
@@ -154,6 +159,46 @@ def test_gemm_batched_strided_and_shift(dev):
             ysh[:, :-1] = yv[:, 1:]
         assert_close(c.cpu().numpy().reshape(G, Hh), dg.astype(np.float64).T @ ysh.reshape(-1, Hh), rtol=2e-5, atol=1e-4,
                      what=f"shift {s}")
+
+    # both directions of a bidirectional layer as ONE batch of two: shift -1 for batch 0, +1 for batch 1 (dW_hh)
+    dg2 = rng.randn(Bq * Tq, 2, G).astype(np.float32)
+    y2 = rng.randn(Bq * Tq, 2, Hh).astype(np.float32)
+    c = run_gemm(dev, T_(dg2, dev), T_(y2, dev), G, Hh, Bq * Tq, 1, 2 * G, 1, 2 * Hh, batch=2, ab=G, bb=Hh, cb=G * Hh, kshift=-1,
+                 kT=Tq, kshift_batch=2)
+    for d, s in enumerate((-1, 1)):
+        yv = y2[:, d].reshape(Bq, Tq, Hh)
+        ysh = np.zeros_like(yv)
+        if s == -1:
+            ysh[:, 1:] = yv[:, :-1]
+        else:
+            ysh[:, :-1] = yv[:, 1:]
+        assert_close(c.cpu().numpy()[d * G * Hh:(d + 1) * G * Hh].reshape(G, Hh), dg2[:, d].astype(np.float64).T @ ysh.reshape(-1, Hh),
+                     rtol=2e-5, atol=1e-4, what=f"batched shift, direction {d}")
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(384, 128, 6400, 2), (256, 256, 4096, 3), (45, 64, 768, 1), (6400, 256, 768, 1), (100, 256, 2048, 5)])
+def test_gemm_split_k_paths(dev, M, N, K, batch):
+    """Long reductions under few output tiles take the split-K paths: slabs summed by the last workgroup to arrive at a tile
+    (few slabs) or by the wide reduce kernels (many slabs).  Same sum order either way: results identical to each other run to
+    run, equal to fp64 within fp32 rounding, fused column sums (bias gradients) included."""
+    rng = np.random.RandomState(M + K)
+    a = rng.randn(batch, K, M).astype(np.float32)     # weight-gradient layout: both operands reduction-strided
+    b = rng.randn(batch, K, N).astype(np.float32)
+    ws = torch.empty(8 << 20, device=dev)
+    cs = torch.zeros(batch * M, device=dev)
+    outs = []
+    for _ in range(2):
+        outs.append(run_gemm(dev, T_(a, dev), T_(b, dev), M, N, K, 1, M, 1, N, batch=batch, ab=K * M, bb=K * N, cb=M * N, splitk_ws=ws,
+                             colsum=cs, colsum_batch=M))
+    assert torch.equal(outs[0], outs[1])              # arrival order does not enter the sum
+    ref = np.einsum("gkm,gkn->gmn", a.astype(np.float64), b)
+    scale = np.abs(ref).max()
+    assert np.abs(outs[0].cpu().numpy()[:batch * M * N].reshape(batch, M, N) - ref).max() <= 2e-6 * scale * np.sqrt(K)
+    assert np.abs(cs.cpu().numpy().reshape(batch, M) - a.astype(np.float64).sum(1)).max() <= 2e-6 * np.sqrt(K) * np.abs(a).max() * 4
+    # input-gradient layout (A reduction-contiguous, B reduction-strided), no column sums
+    a2 = np.ascontiguousarray(a[0].T)                  # [M][K]
+    out = run_gemm(dev, T_(a2, dev), T_(b[0], dev), M, N, K, K, 1, 1, N, splitk_ws=ws)
+    assert np.abs(out.cpu().numpy()[:M * N].reshape(M, N) - ref[0]).max() <= 2e-6 * scale * np.sqrt(K)
 
 
 # ------------------------------------------------------------------------------------------- GRU
