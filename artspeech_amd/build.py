@@ -22,6 +22,7 @@ SOURCES = {
     "gru.hip": [],
     "lstm.hip": [],
     "conv.hip": [],
+    "attention.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
     "artspeech.hip": [],
 }

@@ -1,0 +1,243 @@
+// Fused multi-head attention core for the transformer variant (nn.MultiheadAttention inside ChannelProcessingLayer,
+// transformer/models.py:37-100): ctx = softmax(Q_h K_h^T / sqrt(dh) + attn_mask[b] + key_padding_mask[b]) V_h per
+// (channel pair g, utterance b, head h), exact fp32 on the f32 MFMA, scores never leave the registers.
+//
+// The unfused path (two grouped GEMMs around as_attn_softmax) runs at ~30 TFLOP/s at T = 200, dh = 64: 200 x 200 x 64
+// problems make 4 ragged 128 x 128 tiles with a 2-step reduction, and the 2.25 GB score tensor of one interaction layer
+// goes to HBM and back twice.  Here one workgroup owns one (g, b, h): K_h and V_h are staged once in LDS and every wave
+// takes a strip of 32 queries.
+//
+// Everything is computed TRANSPOSED so that no operand ever has to change layout between the two matrix products:
+//   S^T[key][q]  = sum_c K[key][c] Q[q][c]      A = K rows (LDS), B = the lane's own query row (registers)
+//   O^T[c][q]    = sum_key V[key][c] P^T[key][q] A = V^T (LDS),    B = P^T -- exactly the accumulator registers of S^T
+// The 32x32x2 MFMA returns D[i][j] with j = lane & 31 and i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) for register r, and
+// takes B[k][j] from lane (j, k = lane >> 5).  Pairing the two reduction indices of one MFMA step as (key, key + 4) makes
+// register r of an S^T accumulator -- key_r in the lower half-wave, key_r + 4 in the upper -- the B operand of the second
+// product as it stands.  A query is a lane column, so the softmax statistics are in-lane reductions over the accumulator
+// registers plus ONE exchange between the half-waves.
+#include <cmath>
+
+#include "as_common.h"
+#include "artspeech_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct AttnK {
+    const float* Q; const float* K; const float* V; float* O;
+    const float* mask_t;  // [B][Tk rounded up to 32][T] additive, KEY-major (transposed and padded by the caller) or nullptr
+    const float* kpm;     // [B][Tk] additive or nullptr
+    float* lse;           // [Z][T] row maximum + log of the row sum (for a backward that recomputes P) or nullptr
+    int B, heads, T, Tk, d;
+    float scale;
+};
+
+constexpr int ATT_THREADS = 512;
+
+// DH: head width (16 / 32 / 64).  NB: 32-key blocks held in registers (Tk <= 32 NB).
+template <int DH, int NB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
+    constexpr int LD = DH + 4;                 // LDS row stride: 16-byte aligned rows, conflict-free b128 row reads
+    constexpr int HS = DH / 2;                 // reduction steps of S^T: step s pairs columns (s, s + HS)
+    constexpr int OB = (DH + 31) / 32;         // 32-row blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                          // [32 NB][LD]
+    float* Vs = smem + 32 * NB * LD;           // [32 NB][LD]
+    float* kp = Vs + 32 * NB * LD;             // [32 NB] key padding mask (0 when absent, -inf beyond Tk)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long z = blockIdx.x;
+    const int h = (int)(z % a.heads);
+    const int b = (int)((z / a.heads) % a.B);
+    const long g = z / ((long)a.heads * a.B);
+    const long qbase = ((g * a.B + b) * (long)a.T) * a.d + (long)h * DH;
+    const long kbase = ((g * a.B + b) * (long)a.Tk) * a.d + (long)h * DH;
+
+    // stage K_h, V_h (zero rows beyond Tk) and the key padding mask
+    constexpr int V4 = DH / 4;
+    for (int i = tid; i < 32 * NB * V4; i += ATT_THREADS) {
+        const int row = i / V4, c4 = i - row * V4;
+        const bool ok = row < a.Tk;
+        const long off = kbase + (long)(ok ? row : 0) * a.d + c4 * 4;
+        float4 kv = *reinterpret_cast<const float4*>(a.K + off);
+        float4 vv = *reinterpret_cast<const float4*>(a.V + off);
+        if (!ok) kv = vv = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Ks + row * LD + c4 * 4) = kv;
+        *reinterpret_cast<float4*>(Vs + row * LD + c4 * 4) = vv;
+    }
+    for (int i = tid; i < 32 * NB; i += ATT_THREADS)
+        kp[i] = i < a.Tk ? (a.kpm ? a.kpm[(long)b * a.Tk + i] : 0.f) : -INFINITY;
+    __syncthreads();
+
+    const float* vl = Vs + 4 * lh * LD + l31;  // this lane's corner of V^T: row 4 lh (+ key_r), column l31 (+ 32 ob)
+    const float* kpl = kp + 4 * lh;
+    const int strips = (a.T + 31) / 32;
+    for (int strip = wave; strip < strips; strip += ATT_THREADS / 64) {
+        const int q = strip * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        // the lane's query row, the half of it this half-wave feeds to the MFMA: columns lh*HS + s
+        float qv[HS];
+        {
+            const float* qp = a.Q + qbase + (long)qc * a.d + lh * HS;
+#pragma unroll
+            for (int s = 0; s < HS; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(qp + s);
+                qv[s] = t.x; qv[s + 1] = t.y; qv[s + 2] = t.z; qv[s + 3] = t.w;
+            }
+        }
+        f32x16 sacc[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
+            float kv[HS];
+            const float* kr = Ks + (blk * 32 + l31) * LD + lh * HS;
+#pragma unroll
+            for (int s = 0; s < HS; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(kr + s);
+                kv[s] = t.x; kv[s + 1] = t.y; kv[s + 2] = t.z; kv[s + 3] = t.w;
+            }
+#pragma unroll
+            for (int s = 0; s < HS; ++s) sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[s], qv[s], sacc[blk], 0, 0, 0);
+            // keep the blocks apart: left alone, the scheduler hoists every block's LDS reads to the top and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // scores -> scale + masks; column (= query) maximum
+        float m = -INFINITY;
+        if (a.mask_t) {  // uniform branch around the whole unrolled block, not one per element
+            // uniform row pointer + one per-lane 32-bit offset: per-element 64-bit addresses would be hoisted out of the strip
+            // loop and cost 2 VGPRs each (the mask is padded to 32 NB key rows, so no clamping either)
+            const float* mt = a.mask_t + (long)b * (32 * NB) * a.T;
+            const int moff = qc + 4 * lh * a.T;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {  // 16 loads in flight per block (all NB x 16 at once would not fit the registers)
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = (mt + (long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * a.T)[moff];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[blk][r] = sacc[blk][r] * a.scale + mv[r];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[blk][r] *= a.scale;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = sacc[blk][r] + kpl[blk * 32 + (r & 3) + 8 * (r >> 2)];  // -inf beyond Tk
+                sacc[blk][r] = x;
+                m = fmaxf(m, x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(sacc[blk][r] - m);  // a fully masked query: -inf - -inf = NaN, like PyTorch
+                sacc[blk][r] = e;
+                l += e;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        // O^T = V^T P^T: register r of block blk is the B operand for the key pair (key_r, key_r + 4)
+        f32x16 oacc[OB];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[ob][r] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            float vv[16][OB];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob) {  // lane base + compile-time offset: an immediate of the ds_read
+                    const float t = vl[(blk * 32 + (r & 3) + 8 * (r >> 2)) * LD + ob * 32];
+                    vv[r][ob] = ob * 32 + l31 < DH ? t : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = sacc[blk][r] * inv;
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r][ob], p, oacc[ob], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < a.T) {
+            float* op = a.O + qbase + (long)q * a.d;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {  // rows c = 32 ob + 8 rr + 4 lh + (0..3): one 16-byte store
+                    const int c = ob * 32 + 8 * rr + 4 * lh;
+                    if (c < DH)
+                        *reinterpret_cast<float4*>(op + c) =
+                            make_float4(oacc[ob][4 * rr], oacc[ob][4 * rr + 1], oacc[ob][4 * rr + 2], oacc[ob][4 * rr + 3]);
+                }
+            if (a.lse && lh == 0) a.lse[z * a.T + q] = m + __logf(l);
+        }
+    }
+}
+
+template <int DH, int NB>
+int launch_attn(const AttnK& k, long Z, hipStream_t st) {
+    constexpr size_t shm = (size_t)(2 * 32 * NB * (DH + 4) + 32 * NB) * sizeof(float);
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DH, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    AS_REQUIRE(attr == hipSuccess, (int)attr, "as_attention_fwd: cannot reserve %zu bytes of LDS: %s", shm, hipGetErrorString(attr));
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, NB>), dim3((unsigned)Z), dim3(ATT_THREADS), shm, st, k);
+    return 0;
+}
+
+template <int DH>
+int launch_attn_nb(const AttnK& k, long Z, hipStream_t st) {
+    const int nb = (k.Tk + 31) / 32;
+    if (nb <= 1) return launch_attn<DH, 1>(k, Z, st);
+    if (nb <= 2) return launch_attn<DH, 2>(k, Z, st);
+    if (nb <= 4) return launch_attn<DH, 4>(k, Z, st);
+    if (nb <= 6) return launch_attn<DH, 6>(k, Z, st);
+    if (nb <= 7) return launch_attn<DH, 7>(k, Z, st);
+    return launch_attn<DH, 8>(k, Z, st);
+}
+
+}  // namespace
+
+extern "C" int as_attention_supported(int32_t T, int32_t Tk, int32_t d, int32_t heads) {
+    if (T <= 0 || Tk <= 0 || heads <= 0 || d <= 0 || d % heads != 0) return 0;
+    const int dh = d / heads;
+    return (dh == 16 || dh == 32 || dh == 64) && Tk <= 256;
+}
+
+extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
+                                float* out, float* lse, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d,
+                                float scale, void* stream) {
+    AS_REQUIRE(Q && K && V && out && G > 0 && B > 0 && heads > 0 && T > 0 && Tk > 0 && d > 0, AS_ERR_BAD_ARG, "as_attention_fwd: bad argument");
+    AS_REQUIRE(as_attention_supported(T, Tk, d, heads), AS_ERR_UNSUPPORTED,
+               "as_attention_fwd: head width %d / %d not in {16, 32, 64} or Tk=%d > 256 (use the unfused path)", d, heads, Tk);
+    AS_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
+                 reinterpret_cast<uintptr_t>(out)) & 15) == 0, AS_ERR_BAD_ARG, "as_attention_fwd: operands must be 16-byte aligned");
+    AttnK k;
+    k.Q = Q; k.K = K; k.V = V; k.O = out; k.mask_t = attn_mask_t; k.kpm = key_padding_mask; k.lse = lse;
+    k.B = B; k.heads = heads; k.T = T; k.Tk = Tk; k.d = d; k.scale = scale;
+    const long Z = (long)G * B * heads;
+    hipStream_t st = (hipStream_t)stream;
+    const int dh = d / heads;
+    if (dh == 64) AS_TRY(launch_attn_nb<64>(k, Z, st));
+    else if (dh == 32) AS_TRY(launch_attn_nb<32>(k, Z, st));
+    else AS_TRY(launch_attn_nb<16>(k, Z, st));
+    AS_LAUNCH_CHECK("as_attention_fwd");
+    return 0;
+}

@@ -194,6 +194,25 @@ class GroupedLinear(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+FUSED_ATTENTION = os.environ.get("ARTSPEECH_UNFUSED_ATTENTION") is None  # ablation switch (tools/bench_attention.py)
+_MASK_T = {}
+
+
+def _key_major_mask(attn_mask, Tk, T):
+    """(B, T, Tk) additive mask -> (B, Tk32, T): key-major, keys zero-padded to a multiple of 32 (as_attention_fwd).
+    The same mask tensor serves every attention call of a forward pass: the last few transposes are kept."""
+    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), attn_mask.device)
+    mt = _MASK_T.get(key)
+    if mt is None:
+        B = attn_mask.shape[0]
+        mt = torch.zeros((B, (Tk + 31) // 32 * 32, T), dtype=torch.float32, device=attn_mask.device)
+        mt[:, :Tk] = attn_mask.to(torch.float32).transpose(1, 2)
+        if len(_MASK_T) >= 4:
+            _MASK_T.pop(next(iter(_MASK_T)))
+        _MASK_T[key] = mt
+    return mt
+
+
 class Attention(torch.autograd.Function):
     """Multi-head attention core on projected tensors (nn.MultiheadAttention semantics, float additive masks):
     Q [G, B*T, d], K/V [G, B*Tk, d] -> ctx [G, B*T, d];  P = softmax(Q_h K_h^T / sqrt(dh) + attn_mask[b] + kpm[b])."""
@@ -206,6 +225,15 @@ class Attention(torch.autograd.Function):
         T, Tk, dh = R // B, Rk // B, d // heads
         Z = G * B * heads
         dev = Q.device
+        L = _lib.lib()
+        if FUSED_ATTENTION and not any(ctx.needs_input_grad[:3]) and L.as_attention_supported(T, Tk, d, heads):
+            # inference: scores and probabilities never leave the registers (as_attention_fwd)
+            out = torch.empty_like(Q)
+            mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
+            km = _c(kpm) if kpm is not None else None
+            _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None, G, B,
+                                          heads, T, Tk, d, 1.0 / math.sqrt(dh), _lib.stream_ptr()), "as_attention_fwd")
+            return out
         zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
         zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
         zs = _table(dev, ("zs", Z, T, Tk), lambda: [z * T * Tk for z in range(Z)])

@@ -265,6 +265,20 @@ int as_attn_softmax(float* scores, int64_t Z, int32_t Tq, int32_t Tk, int32_t he
 /* Backward of as_attn_softmax, in place on dprobs: dS = P * (dP - sum_k dP * P) * scale. */
 int as_attn_softmax_bwd(const float* probs, float* dprobs, int64_t Z, int32_t Tq, int32_t Tk, float scale, void* stream);
 
+/* Fused attention core of nn.MultiheadAttention as used by ChannelProcessingLayer (transformer/models.py:37-100), on already
+ * projected tensors:  out[g][b*T + q][h*dh + c] = sum_k softmax_k(Q_h[q] . K_h[k] * scale + attn_mask[b][q][k] + kpm[b][k]) V_h[k][c]
+ *   Q, out : [G][B*T][d]     K, V : [G][B*Tk][d]     dh = d / heads in {16, 32, 64}, Tk <= 256 (as_attention_supported)
+ *   attn_mask_t      : [B][Tk32][T] additive float mask, KEY-major (the transpose of the reference's (B, T, Tk) mask) with
+ *                      the key dimension padded to Tk32 = Tk rounded up to a multiple of 32 (finite padding), or NULL
+ *   key_padding_mask : [B][Tk] additive float mask (0 / -inf) or NULL
+ *   lse              : optional [G*B*heads][T] log-sum-exp of every score row (what a recomputing backward needs), or NULL
+ * Scores and probabilities stay in registers (the unfused path writes G*B*heads*T*Tk floats twice).  A fully masked query
+ * row yields NaN, as in PyTorch. */
+int as_attention_supported(int32_t T, int32_t Tk, int32_t d, int32_t heads);
+int as_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
+                     float* out, float* lse, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale,
+                     void* stream);
+
 /* dst[c][:] = sum over groups g with src[g] == c of part[g][:] (rows of `len` floats; deterministic order): folds
  * the per-block input gradients of a grouped GEMM back onto the channels the blocks read. */
 int as_group_reduce(const float* part, const int32_t* src, int32_t G, int32_t C, int64_t len, float* dst, void* stream);
