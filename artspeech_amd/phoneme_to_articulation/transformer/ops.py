@@ -226,13 +226,19 @@ class Attention(torch.autograd.Function):
         Z = G * B * heads
         dev = Q.device
         L = _lib.lib()
-        if FUSED_ATTENTION and not any(ctx.needs_input_grad[:3]) and L.as_attention_supported(T, Tk, d, heads):
-            # inference: scores and probabilities never leave the registers (as_attention_fwd)
+        scale = 1.0 / math.sqrt(dh)
+        if FUSED_ATTENTION and L.as_attention_supported(T, Tk, d, heads):
+            # scores stay in registers (as_attention_fwd); training additionally keeps the probabilities, key-major
+            training = any(ctx.needs_input_grad[:3])
             out = torch.empty_like(Q)
+            Pt = torch.empty((Z, Tk, T), dtype=torch.float32, device=dev) if training else None
             mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
             km = _c(kpm) if kpm is not None else None
-            _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None, G, B,
-                                          heads, T, Tk, d, 1.0 / math.sqrt(dh), _lib.stream_ptr()), "as_attention_fwd")
+            _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
+                                          _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
+            if training:
+                ctx.save_for_backward(Q, K, V, Pt, out)
+                ctx.meta = (B, heads, scale, None, None, None)
             return out
         zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
         zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
@@ -252,6 +258,8 @@ class Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dctx):
+        if len(ctx.saved_tensors) == 5:
+            return Attention._backward_key_major(ctx, dctx)
         Q, K, V, P = ctx.saved_tensors
         B, heads, scale, zq, zk, zs = ctx.meta
         G, R, d = Q.shape
@@ -269,6 +277,38 @@ class Attention(torch.autograd.Function):
         _gemm(A=dP, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
         _gemm(A=dP, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=1, a_k=Tk, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
         return dQ, dK, dV, None, None, None, None
+
+
+def _attention_backward_key_major(ctx, dctx):
+    """Backward of the fused forward: the same five products as the unfused path, on the KEY-major probabilities
+    P^T [Z][Tk][T] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
+    second pass over the scores."""
+    Q, K, V, Pt, out = ctx.saved_tensors
+    B, heads, scale = ctx.meta[:3]
+    G, R, d = Q.shape
+    Rk = K.shape[1]
+    T, Tk, dh = R // B, Rk // B, d // heads
+    Z = G * B * heads
+    dev = Q.device
+    zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
+    zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
+    zs = _table(dev, ("zs", Z, T, Tk), lambda: [z * T * Tk for z in range(Z)])
+    dctx = _c(dctx)
+    dPt = torch.empty_like(Pt)
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    # dP^T = V dctx^T ; dV = P^T dctx
+    _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
+    _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+    dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B, heads,
+                                                T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
+    # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
+    _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
+    _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+    return dQ, dK, dV, None, None, None, None
+
+
+Attention._backward_key_major = staticmethod(_attention_backward_key_major)
 
 
 class Heads(torch.autograd.Function):

@@ -259,6 +259,44 @@ def test_fused_attention_matches_unfused_and_torch(dev, G, B, T, Tk, d, h):
         assert bad[:, 0, 1].all() and bad.sum().item() == G * d
 
 
+@pytest.mark.parametrize("G,B,T,Tk,d,h", [(2, 3, 7, 13, 32, 2), (2, 2, 50, 64, 64, 2), (1, 2, 33, 200, 256, 4), (2, 2, 200, 200, 256, 4)])
+def test_fused_attention_training_gradients(dev, G, B, T, Tk, d, h):
+    """Training takes the fused forward too (it also leaves the key-major probabilities) and a backward built on them:
+    gradients against float64 autograd of the textbook formula, and against the unfused path."""
+    from artspeech_amd.phoneme_to_articulation.transformer import ops
+    torch.manual_seed(T + Tk)
+    dh = d // h
+    Q = torch.randn(G, B * T, d, device=dev, requires_grad=True)
+    Kt = torch.randn(G, B * Tk, d, device=dev, requires_grad=True)
+    V = torch.randn(G, B * Tk, d, device=dev, requires_grad=True)
+    am = torch.zeros(B, T, Tk, device=dev).masked_fill(torch.rand(B, T, Tk, device=dev) < 0.3, float("-inf"))
+    am[:, :, 0] = 0
+    kpm = torch.zeros(B, Tk, device=dev)
+    kpm[B - 1, Tk - Tk // 3:] = float("-inf")
+    go = torch.randn(G, B * T, d, device=dev)
+
+    def ref(Q, Kt, V):
+        q = Q.view(G, B, T, h, dh).permute(0, 1, 3, 2, 4)
+        k = Kt.view(G, B, Tk, h, dh).permute(0, 1, 3, 2, 4)
+        v = V.view(G, B, Tk, h, dh).permute(0, 1, 3, 2, 4)
+        s = q @ k.transpose(-1, -2) / dh ** 0.5 + am.to(Q.dtype)[None, :, None] + kpm.to(Q.dtype)[None, :, None, None]
+        return (torch.softmax(s, -1) @ v).permute(0, 1, 3, 2, 4).reshape(G, B * T, d)
+    Qd, Kd, Vd = (t.detach().double().requires_grad_() for t in (Q, Kt, V))
+    gref = torch.autograd.grad(ref(Qd, Kd, Vd), (Qd, Kd, Vd), go.double())
+    out = ops.Attention.apply(Q, Kt, V, am, kpm, B, h)
+    assert out.grad_fn is not None and len(out.grad_fn.saved_tensors) == 5     # the fused path (Q, K, V, P^T, out)
+    gf = torch.autograd.grad(out, (Q, Kt, V), go)
+    ops.FUSED_ATTENTION = False
+    try:
+        gu = torch.autograd.grad(ops.Attention.apply(Q, Kt, V, am, kpm, B, h), (Q, Kt, V), go)
+    finally:
+        ops.FUSED_ATTENTION = True
+    for name, a_, u_, r_ in zip("QKV", gf, gu, gref):
+        scale = r_.abs().max().item()
+        assert (a_.double() - r_).abs().max().item() <= 2e-5 * scale, f"d{name}: fused vs float64"
+        assert (a_ - u_).abs().max().item() <= 2e-5 * scale, f"d{name}: fused vs unfused"
+
+
 def _lib_supported(T, Tk, d, h):
     from artspeech_amd import _lib
     return bool(_lib.lib().as_attention_supported(T, Tk, d, h))
