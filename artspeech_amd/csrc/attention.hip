@@ -207,6 +207,119 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
     }
 }
 
+// Backward, first half: dS^T = P^T o (V dctx^T - D) * scale, key-major, without materialising dP.
+// Same transposed product as S^T in the forward (A = V rows from LDS, B = the lane's own dctx row), one 32-key block at a
+// time: nothing has to be kept across blocks here, so the kernel needs ~100 VGPRs and 61 KB of LDS -- two 8-wave workgroups
+// per CU.  D[q] = sum_c dctx[q][c] ctx[q][c] is a per-lane scalar (each half-wave sums its half of the row, one exchange).
+// Replaces a 200 x 200 x 64 grouped GEMM (4 ragged tiles, 2-step reduction) + the softmax-backward sweep: the dP tensor
+// (2.25 GB per interaction group) is neither written nor read.
+struct AttnDsK {
+    const float* V; const float* dctx; const float* ctx; const float* probs_t; float* ds_t;
+    int B, heads, T, Tk, d;
+    float scale;
+};
+
+template <int DH, int NB>
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
+    constexpr int LD = DH + 4;
+    constexpr int HS = DH / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;  // [32 NB][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long z = blockIdx.x;
+    const int h = (int)(z % a.heads);
+    const int b = (int)((z / a.heads) % a.B);
+    const long g = z / ((long)a.heads * a.B);
+    const long qbase = ((g * a.B + b) * (long)a.T) * a.d + (long)h * DH;
+    const long kbase = ((g * a.B + b) * (long)a.Tk) * a.d + (long)h * DH;
+    constexpr int V4 = DH / 4;
+    for (int i = tid; i < 32 * NB * V4; i += ATT_THREADS) {
+        const int row = i / V4, c4 = i - row * V4;
+        const bool ok = row < a.Tk;
+        float4 v = *reinterpret_cast<const float4*>(a.V + kbase + (long)(ok ? row : 0) * a.d + c4 * 4);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Vs + row * LD + c4 * 4) = v;
+    }
+    __syncthreads();
+    const float* pz = a.probs_t + z * (long)a.Tk * a.T;
+    float* dz = a.ds_t + z * (long)a.Tk * a.T;
+    const int strips = (a.T + 31) / 32;
+    for (int strip = wave; strip < strips; strip += ATT_THREADS / 64) {
+        const int q = strip * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        float gv[HS];
+        float D = 0.f;
+        {
+            const float* gp = a.dctx + qbase + (long)qc * a.d + lh * HS;
+            const float* op = a.ctx + qbase + (long)qc * a.d + lh * HS;
+#pragma unroll
+            for (int s = 0; s < HS; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(gp + s);
+                const float4 o = *reinterpret_cast<const float4*>(op + s);
+                gv[s] = t.x; gv[s + 1] = t.y; gv[s + 2] = t.z; gv[s + 3] = t.w;
+                D += t.x * o.x + t.y * o.y + t.z * o.z + t.w * o.w;
+            }
+        }
+        D += __shfl_xor(D, 32, 64);
+        // uniform row pointer + one of two per-lane 32-bit offsets (as in the forward: per-element 64-bit addresses would be
+        // hoisted out of the strip loop, two VGPRs each).  Rows are clamped on the uniform side, so every load is in bounds.
+        const int off0 = qc, off4 = qc + 4 * lh * a.T;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // the block's probabilities go in flight ahead of its MFMAs
+                const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                const float* row = pz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
+                pv[r] = row[ku + 4 < a.Tk ? off4 : off0];
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            float vr[HS];
+            const float* vrow = Vs + (blk * 32 + l31) * LD + lh * HS;
+#pragma unroll
+            for (int s = 0; s < HS; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(vrow + s);
+                vr[s] = t.x; vr[s + 1] = t.y; vr[s + 2] = t.z; vr[s + 3] = t.w;
+            }
+#pragma unroll
+            for (int s = 0; s < HS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[s], gv[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                const bool both = ku + 4 < a.Tk;                    // uniform: rows ku and ku + 4 both exist
+                const bool mine = both || (lh == 0 && ku < a.Tk);   // this half-wave's key row exists
+                float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
+                if (mine && q < a.T) row[both ? off4 : off0] = pv[r] * (acc[r] - D) * a.scale;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int DH, int NB>
+int launch_attn_ds(const AttnDsK& k, long Z, hipStream_t st) {
+    constexpr size_t shm = (size_t)(32 * NB * (DH + 4)) * sizeof(float);
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_ds_kernel<DH, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    AS_REQUIRE(attr == hipSuccess, (int)attr, "as_attention_bwd_ds: cannot reserve %zu bytes of LDS: %s", shm, hipGetErrorString(attr));
+    hipLaunchKernelGGL((attn_ds_kernel<DH, NB>), dim3((unsigned)Z), dim3(ATT_THREADS), shm, st, k);
+    return 0;
+}
+
+template <int DH>
+int launch_attn_ds_nb(const AttnDsK& k, long Z, hipStream_t st) {
+    const int nb = (k.Tk + 31) / 32;
+    if (nb <= 1) return launch_attn_ds<DH, 1>(k, Z, st);
+    if (nb <= 2) return launch_attn_ds<DH, 2>(k, Z, st);
+    if (nb <= 4) return launch_attn_ds<DH, 4>(k, Z, st);
+    if (nb <= 6) return launch_attn_ds<DH, 6>(k, Z, st);
+    if (nb <= 7) return launch_attn_ds<DH, 7>(k, Z, st);
+    return launch_attn_ds<DH, 8>(k, Z, st);
+}
+
 // softmax backward on key-major tensors, two launches:
 //  (1) D[z][q] = sum_c dctx[q][c] ctx[q][c] over the head's columns: a quarter-wave per query row (16 lanes x float4 = 64
 //      floats), consecutive quarter-waves on consecutive heads of the same row -> a wave reads one contiguous 1 KB row;
@@ -353,5 +466,26 @@ extern "C" int as_attn_softmax_bwd_t(const float* probs_t, float* dprobs_t, cons
         hipLaunchKernelGGL(attn_softmax_bwd_t_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, probs_t, dprobs_t, dsum, total, T, plane, scale);
     }
     AS_LAUNCH_CHECK("as_attn_softmax_bwd_t");
+    return 0;
+}
+
+extern "C" int as_attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G,
+                                   int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream) {
+    AS_REQUIRE(V && dctx && ctx && probs_t && ds_t && G > 0 && B > 0 && heads > 0 && T > 0 && Tk > 0 && d > 0, AS_ERR_BAD_ARG,
+               "as_attention_bwd_ds: bad argument");
+    AS_REQUIRE(as_attention_supported(T, Tk, d, heads), AS_ERR_UNSUPPORTED,
+               "as_attention_bwd_ds: head width %d / %d not in {16, 32, 64} or Tk=%d > 256", d, heads, Tk);
+    AS_REQUIRE(((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(dctx) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0,
+               AS_ERR_BAD_ARG, "as_attention_bwd_ds: operands must be 16-byte aligned");
+    AttnDsK k;
+    k.V = V; k.dctx = dctx; k.ctx = ctx; k.probs_t = probs_t; k.ds_t = ds_t;
+    k.B = B; k.heads = heads; k.T = T; k.Tk = Tk; k.d = d; k.scale = scale;
+    const long Z = (long)G * B * heads;
+    hipStream_t st = (hipStream_t)stream;
+    const int dh = d / heads;
+    if (dh == 64) AS_TRY(launch_attn_ds_nb<64>(k, Z, st));
+    else if (dh == 32) AS_TRY(launch_attn_ds_nb<32>(k, Z, st));
+    else AS_TRY(launch_attn_ds_nb<16>(k, Z, st));
+    AS_LAUNCH_CHECK("as_attention_bwd_ds");
     return 0;
 }

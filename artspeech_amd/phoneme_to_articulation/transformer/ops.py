@@ -194,6 +194,7 @@ class GroupedLinear(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+FUSED_DS = os.environ.get("ARTSPEECH_UNFUSED_DS") is None  # ablation: dP GEMM + as_attn_softmax_bwd_t instead of as_attention_bwd_ds
 FUSED_ATTENTION = os.environ.get("ARTSPEECH_UNFUSED_ATTENTION") is None  # ablation switch (tools/bench_attention.py)
 _MASK_T = {}
 
@@ -296,12 +297,17 @@ def _attention_backward_key_major(ctx, dctx):
     dctx = _c(dctx)
     dPt = torch.empty_like(Pt)
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-    # dP^T = V dctx^T ; dV = P^T dctx
-    _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
+    # dV = P^T dctx
     _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
-    dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B, heads,
-                                                T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
+    if FUSED_DS:
+        # dS^T = P^T o (V dctx^T - D) * scale in one kernel: dP is never formed
+        _lib.check(_lib.lib().as_attention_bwd_ds(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T,
+                                                  Tk, d, scale, _lib.stream_ptr()), "as_attention_bwd_ds")
+    else:
+        _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
+        dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B,
+                                                    heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
     # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
     _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
     _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)

@@ -288,6 +288,13 @@ int as_attention_fwd(const float* Q, const float* K, const float* V, const float
 int as_attn_softmax_bwd_t(const float* probs_t, float* dprobs_t, const float* ctx, const float* dctx, float* dsum, int32_t G,
                           int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream);
 
+/* Backward of the attention core, first half, without a dP tensor:
+ *   ds_t[z][k][q] = probs_t[z][k][q] * (sum_c V_h[k][c] dctx[q][h*dh + c] - D[q]) * scale,   D[q] = sum_c dctx[q][c] ctx[q][c]
+ * (= as_attn_softmax_bwd_t applied to dP^T = V dctx^T).  Shapes as as_attention_fwd; ds_t [G*B*heads][Tk][T] is what the
+ * two remaining grouped GEMMs (dQ = dS K, dK = dS^T Q) read. */
+int as_attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G, int32_t B,
+                        int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream);
+
 /* dst[c][:] = sum over groups g with src[g] == c of part[g][:] (rows of `len` floats; deterministic order): folds
  * the per-block input gradients of a grouped GEMM back onto the channels the blocks read. */
 int as_group_reduce(const float* part, const int32_t* src, int32_t G, int32_t C, int64_t len, float* dst, void* stream);
