@@ -335,3 +335,47 @@ def test_pc_autoencoder_keys_and_seeded_init_match_reference():
     assert m.total_parameters == chk["params"] and m.latent_size == 9
     init = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
     assert abs(init - chk["init_abs_sum"]) < 1e-9 * chk["init_abs_sum"]
+
+
+def test_ctypes_structs_match_the_header_layout():
+    """The ctypes mirrors in _lib.py against a C compiler's view of include/artspeech_hip.h (sizes and the offsets of the
+    fields appended this round): a drifted struct would silently shift every later argument."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from artspeech_amd import _lib
+    src = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "artspeech_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu\n", sizeof(as_opts), offsetof(as_opts, dout_presigmoid), sizeof(as_gemm), offsetof(as_gemm, precision),
+           offsetof(as_gemm, b_kshift_batch), sizeof(as_dims));
+    return 0;
+}
+"""
+    inc = os.path.join(ROOT, "include")
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", inc, c, "-o", exe])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(_lib.Opts), _lib.Opts.dout_presigmoid.offset, C.sizeof(_lib.Gemm), _lib.Gemm.precision.offset,
+            _lib.Gemm.b_kshift_batch.offset, C.sizeof(_lib.Dims)]
+    assert got == want, (got, want)
+
+
+def test_key_major_mask_is_transposed_padded_and_cached():
+    """Host side of as_attention_fwd's mask contract: (B, T, Tk) -> (B, Tk rounded up to 32, T), finite padding, one
+    transpose per mask tensor and version."""
+    from artspeech_amd.phoneme_to_articulation.transformer import ops
+    B, T, Tk = 2, 5, 37
+    m = torch.randn(B, T, Tk)
+    m[0, 1, 3] = float("-inf")
+    mt = ops._key_major_mask(m, Tk, T)
+    assert mt.shape == (B, 64, T) and torch.equal(mt[:, :Tk], m.transpose(1, 2)) and torch.equal(mt[:, Tk:], torch.zeros(B, 64 - Tk, T))
+    assert ops._key_major_mask(m, Tk, T) is mt            # same tensor, same version: cached
+    m[0, 0, 0] = 7.0                                      # in-place change bumps the version
+    mt2 = ops._key_major_mask(m, Tk, T)
+    assert mt2 is not mt and mt2[0, 0, 0] == 7.0
