@@ -24,6 +24,8 @@
 // share the CU from the side stream -- no measurable change, the interference is not VALU issue arbitration.)
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "as_common.h"
 
 namespace {
@@ -302,10 +304,10 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
                 const int i = (c * 16 + r) * VW + 2 * pp;
                 const float4 lo = *reinterpret_cast<const float4*>(wd + (long)i * H + k0);
                 const float4 hi = *reinterpret_cast<const float4*>(wd + (long)(i + 1) * H + k0);
-                wt[0][c * (VW / 2) + pp] = f32x2{lo.x, hi.x};
-                wt[1][c * (VW / 2) + pp] = f32x2{lo.y, hi.y};
-                wt[2][c * (VW / 2) + pp] = f32x2{lo.z, hi.z};
-                wt[3][c * (VW / 2) + pp] = f32x2{lo.w, hi.w};
+                // accumulator slot s of the lane at quad position qp works for unit (s + qp) & 3: see the reduction below
+                auto pick = [](const float4& v, int u) { return u == 0 ? v.x : u == 1 ? v.y : u == 2 ? v.z : v.w; };
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) wt[sl][c * (VW / 2) + pp] = f32x2{pick(lo, (sl + (r & 3)) & 3), pick(hi, (sl + (r & 3)) & 3)};
             }
     }
     for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += NT) {  // padded frames feed the time-batched GEMMs as zeros
@@ -325,7 +327,6 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
     float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
     const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl >= 2 ? -1 : 0;
-    const int u0 = (r & 3) == 0 ? -1 : 0, u1 = (r & 3) == 1 ? -1 : 0, u2 = (r & 3) == 2 ? -1 : 0, u3 = (r & 3) == 3 ? -1 : 0;
     struct In { float r, z, n, hn, hprev, dyv; };
     auto load = [&](long fr, bool has_prev) {
         In v;
@@ -336,12 +337,12 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         v.dyv = dyb[fr * 2 * H];
         return v;
     };
-    auto row_sum = [](float v) {  // all-reduce over the 16 lanes of a DPP row
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
-        return v;
+    // Reduce-scatter of the four partial sums over the 16 lanes of a DPP row: the lane at quad position qp needs only the
+    // total of unit qp.  Its slot s holds unit (s + qp) & 3, so the partial for unit qp of the lane t positions further in the
+    // quad sits in that lane's slot (4 - t) & 3: three rotating quad_perm reads, then row_ror 4 and 8 (which keep the quad
+    // position) -- 5 DPP adds instead of 16 moves + 16 adds + the select that an all-reduce of all four sums needs.
+    auto dpp_add = [](float acc, float v, auto ctrl) {
+        return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, true));
     };
     long fr = (long)b * T + t0;
     float dh = 0.f;
@@ -394,10 +395,12 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
                 for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_elementwise_fma(wt[kk][c], g2, a[kk]);
             }
         }
-        const float s0 = row_sum(a[0].x + a[0].y), s1 = row_sum(a[1].x + a[1].y), s2 = row_sum(a[2].x + a[2].y),
-                    s3 = row_sum(a[3].x + a[3].y);
-        const float acc = __int_as_float((__float_as_int(s0) & u0) | (__float_as_int(s1) & u1) | (__float_as_int(s2) & u2) |
-                                         (__float_as_int(s3) & u3));
+        float acc = a[0].x + a[0].y;
+        acc = dpp_add(acc, a[3].x + a[3].y, std::integral_constant<int, 0x39>{});   // quad_perm [1,2,3,0]
+        acc = dpp_add(acc, a[2].x + a[2].y, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+        acc = dpp_add(acc, a[1].x + a[1].y, std::integral_constant<int, 0x93>{});   // quad_perm [3,0,1,2]
+        acc = dpp_add(acc, acc, std::integral_constant<int, 0x124>{});              // row_ror 4
+        acc = dpp_add(acc, acc, std::integral_constant<int, 0x128>{});              // row_ror 8
         dh = dht * z + acc;
         cur_in = nxt;
         fr += dt;
