@@ -613,6 +613,8 @@ int* counters_for(hipStream_t st) {
     for (const Slot& s : slots)
         if (s.dev == dev && s.st == st) return s.p;
     if (slots.size() >= 64) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;  // no allocation inside a stream capture: the reduce kernel then
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     int* p = nullptr;
     if (hipMalloc(&p, COUNTERS * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemsetAsync(p, 0, COUNTERS * sizeof(int), st) != hipSuccess) { (void)hipFree(p); return nullptr; }
