@@ -7,6 +7,9 @@
 //   c' = f c + i g,  h' = o tanh(c')
 // The forward keeps i, f, g, o and c' per frame for the backward; the backward emits the pre-activation gradients (one
 // array: input- and hidden-side pre-activations share them), weight gradients are time-batched GEMMs over them.
+#include <cstdlib>
+#include <type_traits>
+
 #include "as_common.h"
 
 namespace {
@@ -208,6 +211,115 @@ __global__ __launch_bounds__(LPU * H) void lstm_bwd_kernel(const float* __restri
     }
 }
 
+// Backward recurrence, row layout (as gru_bwd_row_kernel): the unit layout above reads all 4H gate gradients per lane quad
+// (32 ds_read_b128 per lane and step at H = 128: 8 waves x 32 x 8 cycles = 2048 LDS cycles, the whole measured step).  Here a
+// ROW of 16 lanes owns 4 hidden units: a lane holds W_hh^T for those 4 columns over 1/16 of the gate rows (the same 128
+// weight VGPRs), reads 4H/16 gate gradients per step (8 ds_read_b128) and the four partial sums are reduce-scattered over
+// the row (rotated accumulator slots: 5 DPP adds, every lane ends with the total of ITS unit).  Lane r of a row plays
+// unit 4 row + (r & 3), gate plane r >> 2 (i, f, g, o).
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bwd_row_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
+                                                             const float* __restrict__ w_hh, const int* __restrict__ lengths, int T,
+                                                             float* __restrict__ dg) {
+    constexpr int NT = 4 * H;
+    constexpr int VL = 4 * H / 16;  // gate rows per lane
+    constexpr int NCH = VL / 4;     // ds_read_b128 per lane and step
+    __shared__ __attribute__((aligned(16))) float gbuf[2][4 * H];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, row = tid >> 4, r = tid & 15;
+    const int qp = r & 3, pl = r >> 2;
+    const int k0 = row * 4, k = k0 + qp;
+    const int len = lengths[b];
+
+    // slot s works for unit (s + qp) & 3; wt[s][2c + pp] = W_hh^T rows (c*16 + r)*4 + 2pp (+1) of that unit's column
+    f32x2 wt[4][VL / 2];
+    {
+        const float* wd = w_hh + (long)dir * 4 * H * H;
+        auto pick = [](const float4& v, int u) { return u == 0 ? v.x : u == 1 ? v.y : u == 2 ? v.z : v.w; };
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int i = (c * 16 + r) * 4 + 2 * pp;
+                const float4 lo = *reinterpret_cast<const float4*>(wd + (long)i * H + k0);
+                const float4 hi = *reinterpret_cast<const float4*>(wd + (long)(i + 1) * H + k0);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) wt[sl][2 * c + pp] = f32x2{pick(lo, (sl + qp) & 3), pick(hi, (sl + qp) & 3)};
+            }
+    }
+    for (long i = (long)len * 4 * H + tid; i < (long)T * 4 * H; i += NT) {  // padded frames feed the time-batched GEMMs as zeros
+        const long t = i / (4 * H), c = i % (4 * H);
+        dg[(((long)b * T + t) * 2 + dir) * 4 * H + c] = 0.f;
+    }
+    if (len <= 0) return;
+
+    const int t0 = dir ? 0 : len - 1;  // opposite to the forward walk
+    const int dt = dir ? 1 : -1;
+    const float* gtb = gates + (long)dir * 5 * H + k;        // + frame * 10H
+    const float* dyb = dy + dir * H + k;                     // + frame * 2H
+    float* dgb = dg + (long)dir * 4 * H + pl * H + k;        // + frame * 8H
+    const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl == 2 ? -1 : 0, m3 = pl == 3 ? -1 : 0;
+    struct In { float i, f, g, o, c, cprev, dyv; };
+    auto load = [&](long fr, bool has_prev) {
+        In v;
+        const float* gp = gtb + fr * 10 * H;
+        v.i = gp[0]; v.f = gp[H]; v.g = gp[2 * H]; v.o = gp[3 * H]; v.c = gp[4 * H];
+        const float cp = gtb[(fr + (has_prev ? dt : 0)) * 10 * H + 4 * H];
+        v.cprev = has_prev ? cp : 0.f;
+        v.dyv = dyb[fr * 2 * H];
+        return v;
+    };
+    auto dpp_add = [](float acc, float v, auto ctrl) {
+        return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    long fr = (long)b * T + t0;
+    float dh = 0.f, dc = 0.f;
+    In cur_in = load(fr, len > 1);
+    for (int s = 0; s < len; ++s) {
+        const int cur = s & 1;
+        const int adv = s + 1 < len ? dt : 0;
+        const In nxt = load(fr + adv, s + 2 < len);
+        const float dht = dh + cur_in.dyv;
+        const float tc = as_tanh(cur_in.c);
+        const float dct = dc + dht * cur_in.o * (1.f - tc * tc);
+        const float p_o = dht * tc * cur_in.o * (1.f - cur_in.o);
+        const float p_i = dct * cur_in.g * cur_in.i * (1.f - cur_in.i);
+        const float p_f = dct * cur_in.cprev * cur_in.f * (1.f - cur_in.f);
+        const float p_g = dct * cur_in.i * (1.f - cur_in.g * cur_in.g);
+        dc = dct * cur_in.f;
+        const float v = __int_as_float((__float_as_int(p_i) & m0) | (__float_as_int(p_f) & m1) | (__float_as_int(p_g) & m2) |
+                                       (__float_as_int(p_o) & m3));
+        gbuf[cur][pl * H + k] = v;
+        dgb[fr * 8 * H] = v;
+        __syncthreads();
+        const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
+        float4 gv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) gv[c] = gq[c * 16 + r];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x2 lo = {gv[c].x, gv[c].y}, hi = {gv[c].z, gv[c].w};
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                a[sl] = __builtin_elementwise_fma(wt[sl][2 * c], lo, a[sl]);
+                a[sl] = __builtin_elementwise_fma(wt[sl][2 * c + 1], hi, a[sl]);
+            }
+        }
+        float acc = a[0].x + a[0].y;
+        acc = dpp_add(acc, a[3].x + a[3].y, std::integral_constant<int, 0x39>{});   // quad_perm [1,2,3,0]
+        acc = dpp_add(acc, a[2].x + a[2].y, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+        acc = dpp_add(acc, a[1].x + a[1].y, std::integral_constant<int, 0x93>{});   // quad_perm [3,0,1,2]
+        acc = dpp_add(acc, acc, std::integral_constant<int, 0x124>{});              // row_ror 4
+        acc = dpp_add(acc, acc, std::integral_constant<int, 0x128>{});              // row_ror 8
+        dh = acc;
+        cur_in = nxt;
+        fr += dt;
+        // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    }
+}
+
 }  // namespace
 
 extern "C" int as_lstm_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
@@ -245,7 +357,10 @@ extern "C" int as_lstm_bidir_bwd(const float* dy, const float* gates, const floa
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_lstm_bidir_bwd: B=%d T=%d", B, T);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B, 2);
-#define AS_LSTM_BWD(HH) hipLaunchKernelGGL((lstm_bwd_kernel<HH>), grid, dim3(LPU * HH), 0, st, dy, gates, w_hh, lengths, T, dg)
+    static const bool unit_layout = getenv("AS_LSTM_BWD_UNIT") != nullptr;  // ablation: the older 4-lanes-per-unit layout
+#define AS_LSTM_BWD(HH)                                                                                                     \
+    if (unit_layout) hipLaunchKernelGGL((lstm_bwd_kernel<HH>), grid, dim3(LPU * HH), 0, st, dy, gates, w_hh, lengths, T, dg); \
+    else hipLaunchKernelGGL((lstm_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, gates, w_hh, lengths, T, dg)
     switch (H) {
         case 32: AS_LSTM_BWD(32); break;
         case 64: AS_LSTM_BWD(64); break;
