@@ -121,6 +121,54 @@ def test_medium_config_vs_oracle(dev):
     model.set_encoder_grad_mode(None)
 
 
+def test_full_size_forward_properties(dev):
+    """BASELINE configs[3] at full size (d=256, 6 layers, 11 articulators, B=32, T=200, ragged lengths): properties that do not
+    need an oracle run -- bitwise run-to-run determinism, batch independence (an utterance's contours do not depend on its
+    batch mates), padding invariance (frames beyond an utterance's length do not influence the valid ones), range."""
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    torch.manual_seed(11)
+    V, A, d, h, L, nf = 45, 11, 256, 4, 6, 100
+    B, T = 32, 200
+    model = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf).to(dev).eval()
+    lens = torch.linspace(T, 60, B).int().tolist()
+
+    def make(idx):
+        g = torch.Generator().manual_seed(5)
+        items = [(f"s{i}", torch.randint(1, V, (l,), generator=g), torch.rand(l, A, 2, nf // 2, generator=g), ["p"] * l,
+                  torch.rand(l, 1, 2, nf // 2, generator=g), torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l))
+                 for i, l in enumerate(lens)]
+        c = pad_sequence_transformer_collate_fn([items[i] for i in idx])
+        tokens, targets = c[1].to(dev), c[2].to(dev)
+        b, t = tokens.shape
+        shifted = torch.cat([torch.zeros(b, 1, A, nf, device=dev), targets[:, 1:].reshape(b, t - 1, A, nf)], dim=1)
+        kw = dict(src_key_padding_mask=c[8].to(dev), tgt_key_padding_mask=c[9].to(dev), src_attn_mask=c[10].to(dev),
+                  tgt_attn_mask=c[11].to(dev))
+        return tokens, shifted, kw, c[3]
+    with torch.no_grad():
+        tokens, shifted, kw, lengths = make(range(B))
+        out = model(tokens, shifted, **kw)
+        assert out.shape == (B, T, A, 2, nf // 2)
+        assert torch.equal(out, model(tokens, shifted, **kw))                          # deterministic, bit for bit
+        valid = torch.arange(T, device=dev)[None, :] < torch.as_tensor(lengths, device=dev)[:, None]
+        ov = out[valid]
+        assert torch.isfinite(ov).all() and ov.min() >= 0 and ov.max() <= 1            # sigmoid contours
+        # batch independence: four of the utterances alone (the collate re-sorts by length: same relative order here)
+        sub = [3, 10, 20, 31]
+        tokens2, shifted2, kw2, lengths2 = make(sub)
+        out2 = model(tokens2, shifted2, **kw2)
+        for j, i in enumerate(sub):
+            l = int(lengths2[j])
+            assert int(lengths[i]) == l
+            assert (out2[j, :l] - out[i, :l]).abs().max().item() <= 2e-5, (i, (out2[j, :l] - out[i, :l]).abs().max().item())
+        # padding invariance: garbage in the padded decoder inputs of the shorter utterances changes nothing valid
+        shifted3 = shifted.clone()
+        pad = ~valid
+        shifted3[pad] = 123.0
+        out3 = model(tokens, shifted3, **kw)
+        assert (out3[valid] - out[valid]).abs().max().item() <= 1e-6
+
+
 # ------------------------------------------------------------------------------------------- training (backward)
 def test_backward_matches_reference_fixture(small, dev):
     """eval mode + gradient tracking (dropout off, standard encoder path): d(sum(out * dout)) / d(every parameter)
