@@ -169,6 +169,53 @@ def test_full_size_forward_properties(dev):
         assert (out3[valid] - out[valid]).abs().max().item() <= 1e-6
 
 
+def test_full_size_training_step_directional_derivative(dev):
+    """configs[3] at full size, training path (fused attention forward with key-major probabilities, dS kernel, grouped
+    GEMM backward): the gradient along its own direction against a central finite difference of the masked loss, and bitwise
+    determinism of loss and gradients."""
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(12)
+    V, A, d, h, L, nf = 45, 11, 256, 4, 6, 100
+    B, T = 32, 200
+    model = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf).to(dev).eval()
+    lens = torch.linspace(T, 60, B).int().tolist()
+    items = [(f"s{i}", torch.randint(1, V, (l,)), torch.rand(l, A, 2, nf // 2), ["p"] * l, torch.rand(l, 1, 2, nf // 2),
+              torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l)) for i, l in enumerate(lens)]
+    c = pad_sequence_transformer_collate_fn(items)
+    tokens, targets, lengths = c[1].to(dev), c[2].to(dev), c[3]
+    shifted = torch.cat([torch.zeros(B, 1, A, nf, device=dev), targets[:, 1:].reshape(B, T - 1, A, nf)], dim=1)
+    kw = dict(src_key_padding_mask=c[8].to(dev), tgt_key_padding_mask=c[9].to(dev), src_attn_mask=c[10].to(dev), tgt_attn_mask=c[11].to(dev))
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def loss_and_grads():
+        for p in params:
+            p.grad = None
+        loss = masked_euclidean_loss(model(tokens, shifted, **kw), targets, lengths)
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in params]
+    l0, g0 = loss_and_grads()
+    l1, g1 = loss_and_grads()
+    assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(g0, g1))                # deterministic, bit for bit
+    assert all(torch.isfinite(g).all() for g in g0)
+    gnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in g0)).item()
+    assert gnorm > 0
+
+    def loss_at(sign):
+        with torch.no_grad():
+            for p, g in zip(params, g0):
+                p.add_(g, alpha=sign * eps)
+            val = masked_euclidean_loss(model(tokens, shifted, **kw), targets, lengths).item()
+            for p, g in zip(params, g0):
+                p.add_(g, alpha=-sign * eps)
+        return val
+    # the loss moves by ~ +-1e-4 (far above its fp32 rounding, ~3e-8); a 16 times longer step is already 17 % off: curvature
+    eps = 1.25e-4 / gnorm
+    fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)                                       # = |grad|^2 along the gradient
+    assert abs(fd - gnorm ** 2) <= 0.03 * gnorm ** 2, (fd, gnorm ** 2)
+
+
 # ------------------------------------------------------------------------------------------- training (backward)
 def test_backward_matches_reference_fixture(small, dev):
     """eval mode + gradient tracking (dropout off, standard encoder path): d(sum(out * dout)) / d(every parameter)
