@@ -151,6 +151,7 @@ class ArtSpeechTransformer(nn.Module):
                 head[o:o + _numel(shape)] = _uniform(shape, fan).reshape(-1)
         P["head_flat"] = head
         self.P = nn.ParameterDict({k: nn.Parameter(v) for k, v in P.items()})
+        self._fold_cache = None  # {key: folded (W, b)} while generate() runs
 
         position = torch.arange(5000).unsqueeze(1)
         div_term = torch.exp(torch.arange(0, d, 2) * (-math.log(10000.0) / d))
@@ -284,6 +285,17 @@ class ArtSpeechTransformer(nn.Module):
         return x
 
     # ------------------------------------------------------------------ decoder
+    def _fold(self, W, gamma, beta, b):
+        """FoldLN with a per-generate() cache: the folded weights depend on the parameters only, and generate() asks for
+        the same ones at every one of its seq_len decoder passes."""
+        cache = self._fold_cache
+        if cache is None:
+            return FoldLN.apply(W, gamma, beta, b)
+        key = (W.data_ptr(), W.shape, gamma.data_ptr(), b.data_ptr())
+        if key not in cache:
+            cache[key] = FoldLN.apply(W, gamma, beta, b)
+        return cache[key]
+
     def _memory_kv(self, l, mem_hat):
         """Source side of the cross-attention blocks of layer l (k / v pre-projections + MHA in-projections of the memory,
         :47-60 and the in_proj of :62-67): depends on the encoder output only, so generate() computes it once per layer
@@ -293,8 +305,8 @@ class ArtSpeechTransformer(nn.Module):
         n = f"dec{l}_"
         ident = tuple(range(sl.stop - sl.start))
         ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
-        wk, bk = FoldLN.apply(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
-        wv, bv = FoldLN.apply(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
+        wk, bk = self._fold(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
+        wv, bv = self._fold(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
         k = GroupedLinear.apply(mem_hat, wk, bk, src_idx, True)
         v = GroupedLinear.apply(mem_hat, wv, bv, src_idx, True)
         in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
@@ -309,15 +321,15 @@ class ArtSpeechTransformer(nn.Module):
         G = sl.stop - sl.start
         ident = tuple(range(G))
         ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
-        wq, bq = FoldLN.apply(P[n + "q_w"][sl], ln_w, ln_b, P[n + "q_b"][sl])
+        wq, bq = self._fold(P[n + "q_w"][sl], ln_w, ln_b, P[n + "q_b"][sl])
         q = GroupedLinear.apply(xhat_tgt, wq, bq, tgt_idx, True)
         in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
         q2 = GroupedLinear.apply(q, in_w[:, :d], in_b[:, :d], ident, False)
         if kv is not None:
             k2, v2 = kv
         else:
-            wk, bk = FoldLN.apply(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
-            wv, bv = FoldLN.apply(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
+            wk, bk = self._fold(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
+            wv, bv = self._fold(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
             k = GroupedLinear.apply(xhat_src, wk, bk, src_idx, True)
             v = GroupedLinear.apply(xhat_src, wv, bv, src_idx, True)
             k2 = GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False)
@@ -344,11 +356,11 @@ class ArtSpeechTransformer(nn.Module):
             phat_q = phat
         inter_blocks = self._blocks(l, "inter", phat_q, phat, tgt_mask, tgt_kpm, B)          # [A*(A-1), R, d]
         cat = inter_blocks.view(A, A - 1, R, d).permute(0, 2, 1, 3).reshape(A, R, (A - 1) * d)  # concat over the other channels
-        wl, bl = FoldLN.apply(P[n + "il_w"], P[n + "il_ln_w"], P[n + "il_ln_b"], P[n + "il_b"])
+        wl, bl = self._fold(P[n + "il_w"], P[n + "il_ln_w"], P[n + "il_ln_b"], P[n + "il_b"])
         inter = GroupedLinear.apply(Normalize.apply(cat), wl, bl, tuple(range(A)), True)      # [A, R, d]
         inp = self._blocks(l, "input", Normalize.apply(inter), mem_hat, memory_mask, mem_kpm, B, kv=mem_kv)
         y = LayerNormAffine.apply(inp, None, P[n + "ln2_w"], P[n + "ln2_b"])
-        wf, bf = FoldLN.apply(P[n + "ff_w"][None], P[n + "ff_ln_w"][None], P[n + "ff_ln_b"][None], P[n + "ff_b"][None])
+        wf, bf = self._fold(P[n + "ff_w"][None], P[n + "ff_ln_w"][None], P[n + "ff_ln_b"][None], P[n + "ff_b"][None])
         ff = GroupedLinear.apply(Normalize.apply(y).view(1, A * R, d), wf, bf, (0,), True).view(A, R, d)
         return y + ff
 
@@ -360,7 +372,7 @@ class ArtSpeechTransformer(nn.Module):
         R = B * T
         train = self.training
         that = Normalize.apply(tgt.reshape(R * A, nf).float())
-        w, b = FoldLN.apply(P["tgt_w"][None], P["tgt_ln_w"][None], P["tgt_ln_b"][None], P["tgt_b"][None])
+        w, b = self._fold(P["tgt_w"][None], P["tgt_ln_w"][None], P["tgt_ln_b"][None], P["tgt_b"][None])
         emb = GroupedLinear.apply(that[None], w, b, (0,), True).view(B, T, A, d)
         x = F.dropout(emb + self.pe[0, :T].view(1, T, 1, d), self.dropout, train)            # positional encoding per channel
         x = x.permute(2, 0, 1, 3).reshape(A, R, d)                                             # channel-major
@@ -372,7 +384,7 @@ class ArtSpeechTransformer(nn.Module):
         if last_only:  # x is [A, B, d]: the newest frame only
             T, R = 1, B
         feat = F.dropout(x.permute(1, 0, 2).reshape(R, A * d), self.dropout, train)
-        w, b = FoldLN.apply(P["fin_w"][None], P["fin_ln_w"][None], P["fin_ln_b"][None], P["fin_b"][None])
+        w, b = self._fold(P["fin_w"][None], P["fin_ln_w"][None], P["fin_ln_b"][None], P["fin_b"][None])
         feat = GroupedLinear.apply(Normalize.apply(feat)[None], w, b, (0,), True)[0]
         out = Heads.apply(feat, P["head_flat"], self.head_dims, self.head_lay)
         return out.view(B, T, A, 2, nf // 2)
@@ -414,11 +426,15 @@ class ArtSpeechTransformer(nn.Module):
             tgt = self.start.repeat(B, 1, 1, 1)
             # the only step-invariant part of the (unmasked, hence non-causal) re-decoding: the memory side of the cross blocks
             memory_kv = None
-            if GENERATE_SAVINGS:
-                mem_hat = Normalize.apply(memory)[None]
-                memory_kv = [self._memory_kv(l, mem_hat) for l in range(self.num_layers)]
-            for _ in range(T):
-                nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm, memory_kv=memory_kv,
-                                              last_only=GENERATE_SAVINGS)
-                tgt = torch.cat([tgt, nxt[:, -1:].reshape(B, 1, self.num_articulators, self.num_feat)], dim=1)
+            self._fold_cache = {} if GENERATE_SAVINGS else None  # folded LayerNorm weights: once per call, not per frame
+            try:
+                if GENERATE_SAVINGS:
+                    mem_hat = Normalize.apply(memory)[None]
+                    memory_kv = [self._memory_kv(l, mem_hat) for l in range(self.num_layers)]
+                for _ in range(T):
+                    nxt = self._generate_one_step(tgt, memory, memory_key_padding_mask=kpm, memory_kv=memory_kv,
+                                                  last_only=GENERATE_SAVINGS)
+                    tgt = torch.cat([tgt, nxt[:, -1:].reshape(B, 1, self.num_articulators, self.num_feat)], dim=1)
+            finally:
+                self._fold_cache = None
             return tgt.reshape(B, T + 1, self.num_articulators, 2, self.num_feat // 2)[:, 1:]
