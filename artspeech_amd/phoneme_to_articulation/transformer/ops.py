@@ -203,15 +203,17 @@ def _key_major_mask(attn_mask, Tk, T):
     """(B, T, Tk) additive mask -> (B, Tk32, T): key-major, keys zero-padded to a multiple of 32 (as_attention_fwd).
     The same mask tensor serves every attention call of a forward pass: the last few transposes are kept."""
     key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), attn_mask.device)
-    mt = _MASK_T.get(key)
-    if mt is None:
+    hit = _MASK_T.get(key)
+    if hit is None:
         B = attn_mask.shape[0]
         mt = torch.zeros((B, (Tk + 31) // 32 * 32, T), dtype=torch.float32, device=attn_mask.device)
         mt[:, :Tk] = attn_mask.to(torch.float32).transpose(1, 2)
         if len(_MASK_T) >= 4:
             _MASK_T.pop(next(iter(_MASK_T)))
-        _MASK_T[key] = mt
-    return mt
+        # the entry keeps the SOURCE tensor alive: its storage cannot be freed and handed to another mask with the same
+        # address, shape and version while the key is in the cache
+        hit = _MASK_T[key] = (attn_mask, mt)
+    return hit[1]
 
 
 class Attention(torch.autograd.Function):
