@@ -33,7 +33,7 @@ struct Carve {
 
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
-    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, total;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, bits1, bits2, total;
 };
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
@@ -63,6 +63,8 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.dw3f = c.take(A * O * D);
     w.slab = c.take(SLAB_FLOATS);   // split-K partial tiles of the weight-gradient GEMMs (main stream)
     w.slab2 = c.take(SLAB_FLOATS);  // same, for GEMMs issued on the side stream
+    w.bits1 = c.take(rows * A * (D / 64) * 2);  // ReLU masks of r1 / r2: one bit per element (64-bit words, 16-byte aligned)
+    w.bits2 = c.take(rows * A * (D / 64) * 2);
     w.total = c.off;
     return w;
 }
@@ -162,11 +164,13 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     AS_STEP("head.norm0", st, as_normalize_fwd(x, ws + w.xhat, ws + w.rstd0, rows, H, st));
     // GEMM 1: all heads at once (shared x_hat): r1 [rows][A*D]
     AS_STEP("head.gemm1", st, gemm_nt(ws + w.xhat, H, ws + w.w1f, H, ws + w.r1, (long)A * D, ws + w.b1f, R, A * D, H, 1, st));
-    AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st));
+    AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st,
+                                               reinterpret_cast<unsigned long long*>(ws + w.bits1)));
     // GEMM 2: batched over heads on [rows][A][D]
     AS_STEP("head.gemm2", st, gemm_nt(ws + w.r1hat, (long)A * D, ws + w.w2f, D, ws + w.r2, (long)A * D, ws + w.b2f, R, D, D, 1, st, A, D,
                    (long)D * D, D, D));
-    AS_STEP("head.norm2", st, as_normalize_fwd(ws + w.r2, ws + w.r2hat, ws + w.rstd2, rows * A, D, st));
+    AS_STEP("head.norm2", st, as_normalize_fwd(ws + w.r2, ws + w.r2hat, ws + w.rstd2, rows * A, D, st,
+                                               reinterpret_cast<unsigned long long*>(ws + w.bits2)));
     // GEMM 3: sigmoid epilogue writes out[rows][A][2][N]
     AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, (long)A * D, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D, (long)O * D, O,
                    O));
@@ -188,9 +192,12 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     const float* dpre3 = presig ? dout : ws + w.dpre3;
     if (!presig) AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
     AS_STEP("headb.dx3", st, gemm_nn(dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
-    AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, ws + w.r2, ws + w.dz2, rows * A, D, st));
+    // the ReLU masks come as bit words (32 B per row) instead of the activations themselves (1 KB per row)
+    AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, nullptr, ws + w.dz2, rows * A, D, st,
+                                                reinterpret_cast<const unsigned long long*>(ws + w.bits2)));
     AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
-    AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, ws + w.r1, ws + w.dz1, rows * A, D, st));
+    AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, nullptr, ws + w.dz1, rows * A, D, st,
+                                                reinterpret_cast<const unsigned long long*>(ws + w.bits1)));
     // N = H columns only (100 x 2 tiles of 64 x 64) under a 2816-long reduction: split K over the main-stream slab
     AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st, 1, 0, 0, 0, ws + w.slab));
     AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));

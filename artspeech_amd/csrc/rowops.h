@@ -2,9 +2,11 @@
 #pragma once
 #include "as_common.h"
 
-int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st);
+// pos_bits (optional): x > 0 per element, ceil(D / 64) 64-bit words per row -- the ReLU mask of a post-ReLU input, which
+// as_normalize_bwd can take as relu_bits instead of re-reading the activation itself (relu_src)
+int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st, unsigned long long* pos_bits = nullptr);
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
-                     int D, hipStream_t st);
+                     int D, hipStream_t st, const unsigned long long* relu_bits = nullptr);
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
             int K, hipStream_t st);
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,

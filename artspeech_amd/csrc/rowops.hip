@@ -15,7 +15,8 @@ constexpr int MAXCW = 44;  // wide rows (transformer: LayerNorm over 10*d / A*d 
 // one wave per row, NW = ceil(D / 64) values per lane; branch-free clamped loads (all in flight together)
 template <int NW>
 __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restrict__ x, float* __restrict__ xhat,
-                                                            float* __restrict__ rstd, long rows, int D, float eps) {
+                                                            float* __restrict__ rstd, long rows, int D, float eps,
+                                                            unsigned long long* __restrict__ pos_bits) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -27,10 +28,12 @@ __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restr
         v[c] = xr[i < D ? i : D - 1];
     }
     float s = 0.f;
+    unsigned long long pos[NW];  // x > 0 per element: the compare result of a wave IS the 64-bit word
 #pragma unroll
     for (int c = 0; c < NW; ++c) {
         if (lane + 64 * c >= D) v[c] = 0.f;
         s += v[c];
+        pos[c] = __ballot(v[c] > 0.f);
     }
     const float mean = as_wave_sum(s) / D;
     float q = 0.f;
@@ -48,6 +51,12 @@ __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restr
         if (i < D) o[i] = v[c] * rs;
     }
     if (lane == 0) rstd[row] = rs;
+    if (pos_bits && lane == 0) {  // ceil(D / 64) words per row: the ReLU mask the backward needs (instead of x itself)
+        const int words = (D + 63) / 64;
+#pragma unroll
+        for (int c = 0; c < NW; ++c)
+            if (c < words) pos_bits[row * words + c] = pos[c];
+    }
 }
 
 // ---- dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) * (relu_src > 0) ------------------------
@@ -56,13 +65,12 @@ template <int MW>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ relu_src, float* dx,
-                                                            long rows, int D) {
+                                                            long rows, int D, const unsigned long long* __restrict__ relu_bits) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* dyr = dy + row * D;
     const float* xr = xhat + row * D;
-    const float* rr = relu_src ? relu_src + row * D : xr;  // no mask: any finite source, the select below ignores it
     float g[MW], h[MW], m[MW];
 #pragma unroll
     for (int c = 0; c < MW; ++c) {  // branch-free clamped loads: everything in flight together
@@ -70,8 +78,25 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
         const int ic = i < D ? i : D - 1;
         g[c] = dyr[ic];
         h[c] = xr[ic];
-        m[c] = rr[ic];
+        m[c] = 1.f;
     }
+    if (relu_src) {  // (one uniform branch around the whole batch, not one per element)
+        const float* rr = relu_src + row * D;
+#pragma unroll
+        for (int c = 0; c < MW; ++c) {
+            const int i = lane + 64 * c;
+            m[c] = rr[i < D ? i : D - 1];
+        }
+    }
+    if (relu_bits) {  // one 64-bit word per 64 elements (a wave-uniform load) instead of a third full-width operand
+        const int words = (D + 63) / 64;
+#pragma unroll
+        for (int c = 0; c < MW; ++c) {
+            const unsigned long long w = relu_bits[row * words + (c < words ? c : words - 1)];
+            m[c] = (w >> lane) & 1ull ? 1.f : 0.f;
+        }
+    }
+    const bool masked = relu_src != nullptr || relu_bits != nullptr;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MW; ++c) {
@@ -87,7 +112,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
         const int i = lane + 64 * c;
         if (i < D) {
             float v = rs * (g[c] - m1 - h[c] * m2);
-            if (relu_src && !(m[c] > 0.f)) v = 0.f;
+            if (masked && !(m[c] > 0.f)) v = 0.f;
             o[i] = v;
         }
     }
@@ -498,9 +523,9 @@ inline int ew_grid(long n) {
 
 }  // namespace
 
-int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st) {
+int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st, unsigned long long* pos_bits) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXC, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXC);
-#define AS_NORM_FWD(NW) hipLaunchKernelGGL(normalize_fwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, x, xhat, rstd, rows, D, 1e-5f)
+#define AS_NORM_FWD(NW) hipLaunchKernelGGL(normalize_fwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, x, xhat, rstd, rows, D, 1e-5f, pos_bits)
     if (D <= 64) AS_NORM_FWD(1);
     else if (D <= 128) AS_NORM_FWD(2);
     else if (D <= 256) AS_NORM_FWD(4);
@@ -510,10 +535,10 @@ int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D,
     return 0;
 }
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
-                     int D, hipStream_t st) {
+                     int D, hipStream_t st, const unsigned long long* relu_bits) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXCW, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXCW);
 #define AS_NORM_BWD(MW) \
-    hipLaunchKernelGGL(normalize_bwd_kernel<MW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D)
+    hipLaunchKernelGGL(normalize_bwd_kernel<MW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D, relu_bits)
     if (D <= 128) AS_NORM_BWD(2);
     else if (D <= 256) AS_NORM_BWD(4);
     else if (D <= 64 * MAXC) AS_NORM_BWD(MAXC);
