@@ -1,21 +1,32 @@
 #!/usr/bin/env python
 """Benchmark of the phoneme_to_articulation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+
+With --gpus N > 1 and no torchrun environment, bench.py starts the N ranks itself as CHILD processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`)
+before it touches the GPU, relays their output and exits with their code; under torchrun (RANK /
+WORLD_SIZE set) it is one of the ranks.
 
 One step = one full training pass of the BiGRU encoder-decoder (BASELINE.json configs[1]) over one
 synthetic batch: forward, masked Euclidean loss, backward to every parameter gradient, one flat RCCL
 all-reduce of the gradients (N > 1) and the flat Adam update.  Inputs are resident in HBM before the
-timed region.  Per rank: B=32 utterances x T=200 frames, A=11 articulators x 50 points, V=45, E=64,
-H=128 (weak scaling: the global batch is 32*N, sharded by utterance).
+timed region.  V=45, E=64, H=128, A=11 articulators x 50 points, T=200.
+  weak scaling (default, the headline `value`): B=32 utterances per GPU, global batch 32*N;
+  strong scaling (configs[2] "same as above, batch-sharded"): ONE global batch of 32 utterances dealt
+  round-robin over the ranks (B=32/N per GPU), loss scaled by the global valid-frame count.
+For N > 1 both are measured back to back and both are in the line (`scaling_runs`).
 
-Prints ONE JSON line on rank 0 (metric: articulator-frames/sec, fwd+bwd).
+Prints ONE JSON line on rank 0 (metric: articulator-frames/sec, fwd+bwd).  At N = 1 the line also
+carries the driver-timed numbers of configs[3] (`transformer_c4`) and configs[4] on one GPU
+(`pipeline_c5_1gpu`), the roofline of the dominant kernels and the CPU baseline.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,28 +35,41 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 V, A, E, H, N = 45, 11, 64, 128, 50
 B, T = 32, 200
+D = 256                      # width of the ArticulatorPredictor hidden layers
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # compulsory HBM bytes of one BiGRU fwd+bwd step at B=32, T=200 = 30.3 KB / frame
 STEP_BYTES_PER_FRAME = 30.3e3
+MAX_REHEARSAL_RANKS = 4      # gloo rehearsal (ranks share one card): the GPU box admits few processes per card
 
 
 def gemm_flops(rows):
-    """Algorithmic FLOPs of each named GEMM phase for `rows` = B*T frames (2 * M * N * K)."""
-    D = 256
-    f = {
+    """Algorithmic FLOPs per STEP of each named GEMM phase for `rows` = B*T frames (2 * M * N * K)."""
+    return {
         "head.gemm1": 2 * rows * A * D * H, "head.gemm2": 2 * rows * A * D * D, "head.gemm3": 2 * rows * A * 2 * N * D,
         "headb.dw3": 2 * rows * A * 2 * N * D, "headb.dx3": 2 * rows * A * 2 * N * D,
         "headb.dw2": 2 * rows * A * D * D, "headb.dx2": 2 * rows * A * D * D,
         "headb.dw1": 2 * rows * A * D * H, "headb.dx1": 2 * rows * A * D * H,
         "gru.xproj1": 2 * rows * 6 * H * 2 * H, "grub.dw_ih1": 2 * rows * 6 * H * 2 * H, "grub.dx1": 2 * rows * 6 * H * 2 * H,
-        "grub.dw_hh": 2 * rows * 3 * H * H, "trunk.linear": 2 * rows * H * 2 * H, "trunkb.dw": 2 * rows * H * 2 * H,
-        "trunkb.dx": 2 * rows * H * 2 * H,
+        "grub.dw_hh": 2 * 2 * rows * 2 * 3 * H * H,   # two layers x two directions
+        "trunk.linear": 2 * rows * H * 2 * H, "trunkb.dw": 2 * rows * H * 2 * H, "trunkb.dx": 2 * rows * H * 2 * H,
+        "gru.table0": 2 * V * 6 * H * E, "grub.dw_ih0": 2 * V * 6 * H * E, "grub.demb": 2 * V * 6 * H * E,
     }
-    return f
+
+
+# GEMM phases grouped by the kernel that runs them, named as rocprofv3 prints it (profiles/r02_kernel_stats.csv)
+GEMM_FAMILIES = {
+    "forward  (C = act(A.B^T + b)): gemm_f32_kernel<*, *, true, true, true>":
+        ["gru.table0", "gru.xproj1", "trunk.linear", "head.gemm1", "head.gemm2", "head.gemm3"],
+    "input gradients (C = A.B): gemm_f32_kernel<*, *, true, false, true>":
+        ["headb.dx3", "headb.dx2", "headb.dx1", "trunkb.dx", "grub.dx1", "grub.demb"],
+    "weight gradients (C = A^T.B): wgrad_f32_kernel / gemm_f32_kernel<64, 64, false, false, true>":
+        ["headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
+}
 
 
 def phase_bytes(rows):
@@ -59,31 +83,22 @@ def phase_bytes(rows):
     }
 
 
-# phase name -> kernel name as rocprofv3 prints it (for the PMC traffic table committed under profiles/)
-PMC_KERNEL = {"gru.bwd_l0": "gru_bwd_row_kernel<128>", "gru.bwd_l1": "gru_bwd_row_kernel<128>",
-              "gru.fwd_l0": "gru_fwd_kernel<128, 4, true, true>", "gru.fwd_l1": "gru_fwd_kernel<128, 4, true, false>"}
+GRU_BWD_KERNEL = "gru_bwd_row_kernel<128>"
 
 
-def pmc_traffic(phase):
-    """HBM bytes per launch of `phase`'s kernel from the committed rocprofv3 --pmc passes (separate
-    FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied: tools/collect_profiles.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if phase not in PMC_KERNEL or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    for name, rec in table.items():
-        if PMC_KERNEL[phase] in name:
-            return rec["hbm_bytes_per_launch"]
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
+    runs, gfx950 correction applied: tools/collect_profiles.py), newest round first, or None."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            table = json.load(f)
+        for name, rec in table.items():
+            if kernel in name:
+                return rec["hbm_bytes_per_launch"]
     return None
-
-
-def make_inputs(dev, seed):
-    g = torch.Generator().manual_seed(seed)
-    tokens = torch.randint(1, V, (B, T), generator=g)
-    targets = torch.rand(B, T, A, 2, N, generator=g)
-    lengths = torch.full((B,), T, dtype=torch.int32)  # throughput runs: all lengths = T (SURVEY 8d)
-    return tokens.to(dev), targets.to(dev), lengths
 
 
 def host_cores():
@@ -134,39 +149,77 @@ def cpu_baseline(state_dict, seconds=12.0):
                       f"(torch {torch.__version__}, {cores} threads), {el:.1f} s"}
 
 
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: start the N ranks as child processes.  Nothing here initialises the GPU
+    (device_count() only counts), and the parent never execs: it waits for the children and returns their code."""
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        if ndev < 1:
+            raise SystemExit("bench.py needs an MI355X")
+        if args.gpus > MAX_REHEARSAL_RANKS:
+            raise SystemExit(f"--gpus {args.gpus} but only {ndev} GPU(s) visible: a shared-card rehearsal is limited to "
+                             f"{MAX_REHEARSAL_RANKS} ranks")
+        # fewer cards than ranks: rehearse the multi-rank code path with the ranks sharing the visible card(s);
+        # RCCL needs one device per rank, so the collectives go through gloo (correctness only, slow)
+        env["ARTSPEECH_DIST_BACKEND"] = "gloo"
+        log(f"{ndev} GPU(s) visible < --gpus {args.gpus}: REHEARSAL, ranks share the card, gloo collectives")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("launching: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def make_batch(n_utt, seed):
+    g = torch.Generator().manual_seed(seed)
+    tokens = torch.randint(1, V, (n_utt, T), generator=g)
+    targets = torch.rand(n_utt, T, A, 2, N, generator=g)
+    lengths = torch.full((n_utt,), T, dtype=torch.int32)  # throughput runs: all lengths = T (SURVEY 8d)
+    return tokens, targets, lengths
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="which run is the headline `value` (N > 1 measures both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (roofline = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] measurements (N = 1)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if B % world:
+        raise SystemExit(f"--gpus {world} does not divide the global batch of {B} utterances")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    if os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks share the visible GPU(s)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm (one rank per GPU over xGMI); ARTSPEECH_DIST_BACKEND=gloo lets several ranks share ONE
-        # GPU to rehearse the multi-rank code path on a single-GPU box (slow collectives, correctness only)
-        backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")
+        # "nccl" is RCCL on ROCm (one rank per GPU over xGMI); gloo = shared-card rehearsal (see self_launch)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from artspeech_amd import _lib
+    from artspeech_amd.distributed import loss_scale, shard_batch
     from artspeech_amd.engine import TrainStep
     from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
 
@@ -174,50 +227,72 @@ def main():
     model = ArtSpeech(V, A, embed_dim=E, hidden_size=H, n_samples=N)
     state_dict = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    tokens, targets, lengths = make_inputs(dev, seed=1 + rank)  # each rank holds its own shard of utterances
-    lengths_dev = lengths.to(dev)
-    n_valid_global = int(lengths.sum()) * world
-    scale = 1.0 / (n_valid_global * A * N)
-    step = TrainStep(model, B, T, lr=1e-4, weight_decay=1e-6)
+    flat0 = model.flat.data.clone()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: warm-up {args.warmup} steps ...")
-    for _ in range(args.warmup):
-        step.step(tokens, lengths_dev, targets, scale)
-    barrier()
-    log("timed region ...")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.step(tokens, lengths_dev, targets, scale)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    loss_t = step.loss.detach().clone().reshape(1)
-    if world > 1:
-        dist.all_reduce(loss_t)  # shard losses are scaled by the global frame count: their SUM is the batch loss
-    loss = float(loss_t.item())
-    assert np.isfinite(loss), "loss is not finite"
+    def measure(mode):
+        """W warm-up + K timed steps of `mode`; returns (elapsed max over ranks, loss, TrainStep, inputs)."""
+        model.flat.data.copy_(flat0)  # every run starts from the same parameters
+        if mode == "weak":     # each rank holds its own batch of B utterances
+            tokens, targets, lengths = make_batch(B, seed=1 + rank)
+            n_valid_global = int(lengths.sum()) * world
+        else:                  # one global batch of B utterances, dealt round-robin (artspeech_amd/distributed.py)
+            tokens, targets, lengths = make_batch(B, seed=1)
+            tokens, targets, lengths, n_valid_global = shard_batch(tokens, targets, lengths, rank, world)
+        b_local = tokens.shape[0]
+        tokens, targets = tokens.contiguous().to(dev), targets.contiguous().to(dev)
+        lengths_dev = lengths.to(torch.int32).to(dev)
+        scale = loss_scale(n_valid_global, A, N)
+        step = TrainStep(model, b_local, T, lr=1e-4, weight_decay=1e-6)
+        log(f"rank {rank}/{world} [{mode}]: B={b_local} per rank, warm-up {args.warmup} steps ...")
+        for _ in range(args.warmup):
+            step.step(tokens, lengths_dev, targets, scale)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.step(tokens, lengths_dev, targets, scale)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        loss_t = step.loss.detach().clone().reshape(1)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            dist.all_reduce(loss_t)  # shard losses are scaled by the global frame count: their SUM is the batch loss
+        loss = float(loss_t.item())
+        assert np.isfinite(loss), "loss is not finite"
+        frames = b_local * T * world * args.steps
+        rec = {"scaling": mode, "value": round(frames / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+               "per_gpu_batch": b_local, "global_batch": b_local * world, "loss": round(loss, 6)}
+        log(f"[{mode}] {rec['ms_per_step']:.3f} ms/step, {rec['value']:.0f} frames/s, loss {loss:.6f}")
+        return rec, step, (tokens, lengths_dev, targets, scale)
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    log(f"{ms_per_step:.3f} ms/step, loss {loss:.6f}")
-    frames = B * T * world * args.steps
-    value = frames / elapsed
+    modes = [args.scaling] + ([m for m in ("weak", "strong") if m != args.scaling] if world > 1 else [])
+    runs = {}
+    head_step = head_inputs = None
+    for m in modes:
+        rec, st, inp = measure(m)
+        runs[m] = rec
+        if m == args.scaling:
+            head_step, head_inputs = st, inp
+        else:
+            del st, inp
+    head = runs[args.scaling]
+    ms_per_step = head["ms_per_step"]
 
-    # ---- instrumented pass (rank 0): per-kernel-phase HIP events on the launch stream ----------------
+    # ---- instrumented pass (rank 0): per-kernel-phase HIP events on each phase's own launch stream ----------------
     roofline, kernels = None, None
     if rank == 0 and not args.no_profile:
+        step = head_step
+        tokens, lengths_dev, targets, scale = head_inputs
         L = _lib.lib()
         psteps = min(args.steps, 20)
         L.as_profile_reset()  # same configuration as the timed region (side-stream overlap on)
         L.as_profile_enable(1)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * psteps)]
         for i in range(psteps):
             step.forward_backward(tokens, lengths_dev, targets, scale)
         torch.cuda.synchronize()
@@ -229,50 +304,86 @@ def main():
         for line in buf.value.decode().splitlines():
             name, cnt, ms = line.split()
             kernels[name] = {"launches_per_step": int(cnt) / psteps, "us_per_step": round(1e3 * float(ms) / psteps, 2)}
-        rows = B * T
+        rows = head["per_gpu_batch"] * T
         flops, nbytes = gemm_flops(rows), phase_bytes(rows)
-        # the two layers' backward recurrences are launches of ONE kernel: judge it as such (its rocprofv3 summary line under
-        # profiles/ averages over both), then pick the kernel that costs most per step
-        merged = dict(kernels)
-        if "gru.bwd_l0" in merged and "gru.bwd_l1" in merged:
-            a, b2 = merged.pop("gru.bwd_l0"), merged.pop("gru.bwd_l1")
-            merged["gru.bwd_l1"] = {"launches_per_step": a["launches_per_step"] + b2["launches_per_step"],
-                                    "us_per_step": a["us_per_step"] + b2["us_per_step"]}
-        dom = max(merged, key=lambda k: merged[k]["us_per_step"])
-        per_launch_us = merged[dom]["us_per_step"] / merged[dom]["launches_per_step"]
-        if dom in flops:
-            per_launch = flops[dom] / merged[dom]["launches_per_step"] if dom == "grub.dw_hh" else flops[dom]
-            ach = per_launch / (per_launch_us * 1e-6) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "us_per_launch": round(per_launch_us, 2), "algorithmic_flops_per_launch": per_launch}
-        else:
-            per_launch = nbytes.get(dom, 0)
+        # (1) the HBM-side entry: the backward recurrence, ONE kernel launched twice per step (layer 1, layer 0)
+        gb = [kernels[k] for k in ("gru.bwd_l0", "gru.bwd_l1") if k in kernels]
+        if gb:
+            per_launch_us = sum(k["us_per_step"] for k in gb) / sum(k["launches_per_step"] for k in gb)
+            per_launch = nbytes["gru.bwd_l1"]
             ach = per_launch / (per_launch_us * 1e-6) / 1e9
-            kname = "gru_bwd_row_kernel<128> (gru.bwd_l0 + gru.bwd_l1)" if dom == "gru.bwd_l1" else dom
-            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom), "us_per_launch": round(per_launch_us, 2),
+            roofline = {"kernel": f"{GRU_BWD_KERNEL} (gru.bwd_l0 + gru.bwd_l1)", "bound": "hbm", "achieved": round(ach, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic(GRU_BWD_KERNEL), "us_per_launch": round(per_launch_us, 2),
                         "algorithmic_bytes_per_launch": per_launch,
                         "note": "dependent-step (latency) bound: 200 sequential recurrent steps per launch"}
-        # whole-step view asked for by the north star: compulsory bytes of SURVEY 8(d) over the step time
-        step_gbs = STEP_BYTES_PER_FRAME * B * T / (ms_per_step * 1e-3) / 1e9
-        roofline["step_hbm"] = {"algorithmic_bytes_per_step": STEP_BYTES_PER_FRAME * B * T, "achieved_GBs": round(step_gbs, 1),
+        else:
+            roofline = {}
+        # (2) the matrix side: every GEMM phase grouped by the kernel that runs it; FLOPs / time / fp32-MFMA peak.
+        # The times are in-step (side-stream GEMMs share the chip with the recurrences), summed per family.
+        fam, tot_f, tot_us = {}, 0.0, 0.0
+        for name, phases in GEMM_FAMILIES.items():
+            present = [p for p in phases if p in kernels]
+            f = sum(flops[p] for p in present)
+            us = sum(kernels[p]["us_per_step"] for p in present)
+            if us <= 0:
+                continue
+            tf = f / (us * 1e-6) / 1e12
+            fam[name] = {"flops_per_step": f, "us_per_step": round(us, 1), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                         "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 3),
+                         "phases": {p: round(flops[p] / (kernels[p]["us_per_step"] * 1e-6) / 1e12, 1) for p in present}}
+            tot_f += f
+            tot_us += us
+        top = max(fam, key=lambda k: fam[k]["us_per_step"]) if fam else None
+        roofline["gemm"] = {"bound": "mfma", "top_family": top, "families": fam,
+                            "all": {"flops_per_step": tot_f, "us_per_step": round(tot_us, 1),
+                                    "achieved": round(tot_f / (tot_us * 1e-6) / 1e12, 1) if tot_us else None,
+                                    "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
+                                    "frac": round(tot_f / (tot_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3) if tot_us else None}}
+        # (3) whole-step view asked for by the north star: compulsory bytes of SURVEY 8(d) over the step time
+        step_gbs = STEP_BYTES_PER_FRAME * rows / (ms_per_step * 1e-3) / 1e9
+        roofline["step_hbm"] = {"algorithmic_bytes_per_step": STEP_BYTES_PER_FRAME * rows, "achieved_GBs": round(step_gbs, 1),
                                 "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 5)}
+    del head_step, head_inputs
 
     if rank == 0:
+        extras = {}
+        if world == 1 and not args.no_extras:
+            # configs[3] / configs[4] on this GPU, timed by the same command (their own workloads, not `value`)
+            torch.cuda.empty_cache()
+            try:
+                import bench_pipeline
+                import bench_transformer
+                t_ = bench_transformer.run(32, 200, 3, dev, log)
+                c4 = dict(t_["fwd_bwd"])
+                c4.update({"workload": "ArtSpeechTransformer d=256 L=6 heads=4 A=11, B=32 T=200, fwd + masked loss + bwd, fp32",
+                           "params": t_["params"], "fwd_only": t_["fwd"]})
+                extras["transformer_c4"] = c4
+                p_ = bench_pipeline.run(32, 200, 3, dev, log)
+                p_["workload"] = ("transformer forward -> tract variables -> area function + resampling -> DeepSpeech2 scorer "
+                                  "top-1, B=32 T=200, one GPU (configs[4] shards utterances over 8)")
+                extras["pipeline_c5_1gpu"] = p_
+            except Exception as exc:  # the headline must survive a failure of the extras
+                extras["extras_error"] = f"{type(exc).__name__}: {exc}"
+                log(f"extras failed: {extras['extras_error']}")
         result = {
-            "metric": "articulator-frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "encoder_decoder BiGRU (ArtSpeech) V=45 E=64 H=128, 11 articulators x 50 pts, "
-                                   "B=32 T=200 per GPU, all lengths 200; step = fwd + masked Euclidean loss + bwd + "
-                                   "flat grad all-reduce + Adam",
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
-            "loss": round(loss, 6),
+            "metric": "articulator-frames/sec (fwd+bwd)", "value": head["value"], "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"encoder_decoder BiGRU (ArtSpeech) V=45 E=64 H=128, 11 articulators x 50 pts, T=200, "
+                                   f"B={head['per_gpu_batch']} per GPU ({args.scaling} scaling), all lengths 200; step = fwd + "
+                                   "masked Euclidean loss + bwd + flat grad all-reduce + Adam",
+                       "global_batch": head["global_batch"], "seq_len": T, "parallelism": f"dp{world}"},
+            "loss": head["loss"],
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "rehearsal_shared_gpu": bool(world > 1 and backend != "nccl"),
+            "scaling_runs": runs,
             "roofline": roofline,
             "kernels_us_per_step": kernels,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(state_dict),  # rank 0 at N = 1 only
         }
+        result.update(extras)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
