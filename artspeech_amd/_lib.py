@@ -42,7 +42,7 @@ class Gemm(C.Structure):
                 ("b_kshift", C.c_int32), ("b_kT", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64), ("colsum", C.c_void_p),
                 ("colsum_batch", C.c_int64), ("a_off", C.c_void_p), ("b_off", C.c_void_p), ("c_off", C.c_void_p),
-                ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32)]
+                ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32), ("cu_budget", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

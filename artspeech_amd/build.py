@@ -18,6 +18,7 @@ SOURCES = {
     "error.cpp": [],
     "prof.hip": [],
     "gemm_f32.hip": [],
+    "wgrad_f32.hip": [],
     "rowops.hip": [],
     "gru.hip": [],
     "lstm.hip": [],

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int D = AS_HEAD_HIDDEN;
-constexpr int64_t SLAB_FLOATS = 8LL << 20;  // 32 MB: ~1024 partial 64x64 tiles + margin
+constexpr int64_t SLAB_FLOATS = 16LL << 20;  // 64 MB of split-K partial tiles per stream
 
 struct Carve {
     int64_t off = 0;
@@ -134,14 +134,15 @@ int gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long 
 }
 // C[M][N] = A[K][M]^T . B[K][N]   (weight gradient: reduction over the rows of both)
 // colsum (optional): column sums of A, i.e. the bias gradient that goes with this weight gradient, [batch][M]
+// cu_budget: CUs the launch can count on (0 = all): 192 for the side stream's launches beside a 64-workgroup recurrence
 int gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, hipStream_t st,
             float* slab, float* colsum = nullptr, long csb = 0, int batch = 1, long ab = 0, long bb = 0, long cb = 0,
-            int kshift = 0, int kT = 0, int kshift_batch = 0) {
+            int kshift = 0, int kT = 0, int kshift_batch = 0, int cu_budget = 0) {
     as_gemm g{};
     g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
     g.a_i = 1; g.a_k = lda; g.b_j = 1; g.b_k = ldb; g.ldc = ldc;
     g.batch = batch; g.a_batch = ab; g.b_batch = bb; g.c_batch = cb; g.b_kshift = kshift; g.b_kT = kT; g.b_kshift_batch = kshift_batch;
-    g.splitk_ws = slab; g.splitk_ws_floats = SLAB_FLOATS; g.colsum = colsum; g.colsum_batch = csb;
+    g.splitk_ws = slab; g.splitk_ws_floats = SLAB_FLOATS; g.colsum = colsum; g.colsum_batch = csb; g.cu_budget = cu_budget;
     return as_gemm_f32(&g, st);
 }
 
@@ -205,16 +206,16 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
 }
 
 int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* G, float* ws, float* slab,
-                hipStream_t st, const float* dpre3_in = nullptr) {
+                hipStream_t st, const float* dpre3_in = nullptr, int cu_budget = 0) {
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
     // each weight-gradient GEMM also emits the bias gradient = column sums of its A operand
     const float* dpre3 = dpre3_in ? dpre3_in : ws + w.dpre3;
-    AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D));
-    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D));
-    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0));
+    AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
+    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
+    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
     // unfold the LayerNorm affines
     AS_STEP("headb.unfold", st, as_unfold(ws + w.dw3f, G + L.b3, P + L.w3, P + L.ln3_g, P + L.ln3_b, G + L.w3, G + L.ln3_g, G + L.ln3_b, A, O, D, st));
     AS_STEP("headb.unfold", st, as_unfold(ws + w.dw2f, G + L.b2, P + L.w2, P + L.ln2_g, P + L.ln2_b, G + L.w2, G + L.ln2_g, G + L.ln2_b, A, D, D, st));
@@ -444,7 +445,8 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
-    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3));
+    const int side_cus = sd ? 192 : 0;  // the recurrence's 2 * B workgroups hold 64 CUs while the side stream works
+    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_TRY(record_heads_done(s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));

@@ -12,7 +12,7 @@
 #include <mutex>
 #include <vector>
 
-#include "as_common.h"
+#include "gemm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -665,6 +665,10 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     AS_REQUIRE(g->act >= 0 && g->act <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
     const bool a_kc = g->a_k == 1, b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
+    if (!a_kc && !b_kc) {  // weight-gradient shapes: the kernel of wgrad_f32.hip
+        const int taken = as_wgrad_try(g, (hipStream_t)stream);
+        if (taken != 0) return taken < 0 ? taken : 0;
+    }
     GemmK k;
     k.A = g->A; k.B = g->B; k.C = g->C; k.bias = g->bias;
     k.M = g->M; k.N = g->N; k.K = g->K;

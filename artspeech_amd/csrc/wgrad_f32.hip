@@ -1,0 +1,311 @@
+// Weight-gradient GEMM  C[g][M][N] = sum_k A[g][k][m] * B[g][k][n]  (both operands reduction-strided: the rows of A and B
+// are the frames, dW = dY^T X) on the fp32 matrix core.  This is the shape behind every nn.Linear / GRU weight gradient of
+// the path (encoder_decoder/models.py:7-33, 111, 113-116 through autograd): a small output (at most a few hundred columns
+// per batch member) under a reduction over all B*T frames.
+//
+// Why a kernel of its own (gemm_f32.hip's general kernel serves it with 64x64 tiles + split-K):
+//   * with 64x64 (or 128x128) output tiles every k-panel of A and B is fetched by 4 (2) sibling workgroups that sit on
+//     different XCDs, i.e. different L2s -- the launch moves 2-4x its operand bytes through the fabric.  Here ONE workgroup
+//     owns a 128 x 256 (or 128 x 128) output tile, so for the head layers (N <= 256) a B panel is fetched by the M-tiles of
+//     one XCD only (the block index -> work map puts the M-tiles of a (batch, k-slab, n-tile) on one XCD, back to back);
+//   * 8 waves (2 per SIMD), each with a 64 x 64 (64 x 32) sub-tile = 4 (2) MFMAs per 2 + 2 (2 + 1) operand reads;
+//   * LDS double buffer with ONE barrier per 16-deep k-tile; the image is a straight copy of the global rows ([k][m]),
+//     which already is what an MFMA operand wants (lane i reads column i of row k: conflict-free ds_read_b32);
+//   * the fused bias gradient (column sums of A) comes out of the staging registers, not out of extra LDS reads;
+//   * deterministic split-K over slabs with a wide reduce kernel (fixed summation order: results do not depend on the
+//     order in which workgroups are scheduled).
+#include <cstdlib>
+
+#include "gemm_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BK = 32, NT = 512, NBUF = 3;
+
+struct WgradK {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long a_batch, b_batch, c_batch;
+    const long* a_off; const long* b_off; const long* c_off;
+    int batch, tiles_m, tiles_n, splitk, kchunk;
+    long ncombos;
+    int per_xcd;
+    int b_kshift, b_kT, b_kshift_batch;
+    int accumulate, c_vec;
+    float* slab;     // [splitk][batch][M][N]
+    float* cs_slab;  // [splitk][batch][M]
+    float* colsum; long colsum_batch;
+    int abl;  // diagnostic ablation (AS_WGRAD_ABL=1): no global loads after the first two k-tiles (matrix work only)
+};
+
+// LDS-DMA helper: one wave-instruction copies 64 x 16 B from per-lane global addresses to 1 KiB of LDS starting at the
+// wave-uniform `dst` (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt)
+__device__ __forceinline__ void glds16(const float* src, float* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(NT, 2) void wgrad_f32_kernel(WgradK g) {
+    constexpr int WN = BN / 4, TN = WN / 32, TM = 2;   // 2 x 4 waves; a wave owns 64 rows x WN columns
+    constexpr int TILE = BK * (BM + BN);                // floats per ring slot: A image [BK][BM] then B image [BK][BN]
+    constexpr int PA = BK * BM / 256 / 8;               // 1-KiB DMA pieces of A per wave and k-tile (2)
+    constexpr int PB = BK * BN / 256 / 8;               // ... of B (4 at BN = 256, 2 at BN = 128)
+    constexpr int RB = 256 / BN;                        // B rows per piece (1 or 2)
+    // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain the DMAs before every read)
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * TILE];
+
+    // block -> work: blocks b and b + 8 share an XCD (round-robin dispatch; speed only).  Work items are ordered
+    // (batch, k-slab, n-tile, m-tile) and every XCD takes one contiguous eighth of them: the M-tiles of one
+    // (batch, k-slab, n-tile) combination, which read the same B panel, sit on one XCD (two at a seam), and the XCDs get
+    // equal shares whatever the counts are.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= g.per_xcd) return;
+    const long item = (long)xcd * g.per_xcd + slot;
+    if (item >= g.ncombos * g.tiles_m) return;
+    const int tm = (int)(item % g.tiles_m);
+    const long combo = item / g.tiles_m;
+    const int tn = (int)(combo % g.tiles_n);
+    const long rest = combo / g.tiles_n;
+    const int ks = (int)(rest % g.splitk), bz = (int)(rest / g.splitk);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);   // both multiples of BK (host contract)
+    const float* __restrict__ A = g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch);
+    const float* __restrict__ B = g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const bool do_cs = g.colsum != nullptr && tn == 0;
+
+    // DMA sources.  A piece = 2 rows x 128 floats: lanes 0-31 row r, lanes 32-63 row r + 1.  Columns beyond M / N are
+    // redirected to the last valid float4 of the row: they only feed output rows / columns that are never stored.
+    const int a_col = min(m0 + l31 * 4, g.M - 4);
+    const float* a_src = A + (long)(kbeg + wave * PA * 2 + lh) * g.lda + a_col;           // + j * 2 rows, + kt * BK rows
+    const int b_lane_col = RB == 1 ? lane * 4 : l31 * 4;
+    const int b_col = min(n0 + b_lane_col, g.N - 4);
+    const float* b_src = B + (long)(kbeg + wave * PB * RB + (RB == 2 ? lh : 0)) * g.ldb + b_col;  // + j * RB rows
+    float* const a_dst = smem + wave * PA * 256;             // + j * 256, + slot * TILE
+    float* const b_dst = smem + BK * BM + wave * PB * 256;
+    auto issue = [&](int kt) {  // the PA + PB DMA pieces of this wave for k-tile kt
+        float* base = smem + (kt % NBUF) * TILE;
+        const long koff = (long)kt * BK;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) glds16(a_src + (koff + j * 2) * g.lda, base + (a_dst - smem) + j * 256);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) glds16(b_src + (koff + j * RB) * g.ldb, base + (b_dst - smem) + j * 256);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float cs = 0.f;  // bias gradient: this thread sums column tid & 127 over rows (tid >> 7) * 8 .. + 7 of every k-tile
+
+    const int nk = (kend - kbeg) / BK;
+    // Ring of NBUF = 3 slots: while k-tile t is multiplied, t + 1 and t + 2 are in flight (2 x 48 KB per CU at BN = 256).
+    // A counted vmcnt retires tile t + 1 at the END of iteration t (it was issued at the start of iteration t - 1: two
+    // iterations of matrix work to land), then a raw barrier publishes it; __syncthreads() would drain every DMA.
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        // slot (kt + 2) % 3 was read in iteration kt - 1; every wave passed the barrier that ended it
+        if (kt + 2 < nk && g.abl != 1) issue(kt + 2);
+        const float* tile = smem + (kt % NBUF) * TILE;
+        const float* a_s = tile + wm * 64 + l31;
+        const float* b_s = tile + BK * BM + wn * WN + l31;
+        if (do_cs) {
+            const float* c_s = tile + (tid >> 7) * 8 * BM + (tid & 127);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cs += c_s[r * BM];
+        }
+        // operands of k-step kk + 1 are read before the MFMAs of k-step kk are issued (their LDS latency hides behind them)
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = a_s[lh * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = b_s[lh * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int c = (kk >> 1) & 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[c ^ 1][i] = a_s[(kk + 2 + lh) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[c ^ 1][j] = b_s[(kk + 2 + lh) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (hipcc otherwise sinks them to their use)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+        }
+        // retire tile kt + 1 (leave kt + 2 in flight), then publish it
+        if (kt + 2 < nk && g.abl != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of slot kt % 3 are done
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- bias gradient: the four row groups of a column meet in LDS, summed in a fixed order
+    if (do_cs) {
+        smem[tid] = cs;   // every fragment read and every DMA is behind the loop's last barrier
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            const float s = ((smem[tid] + smem[BM + tid]) + smem[2 * BM + tid]) + smem[3 * BM + tid];
+            if (g.splitk > 1) g.cs_slab[((long)ks * g.batch + bz) * g.M + m0 + tid] = s;
+            else g.colsum[(long)bz * g.colsum_batch + m0 + tid] = s;
+        }
+    }
+
+    // ---- epilogue: D[i][j], j = lane & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* out;
+    long ld;
+    if (g.splitk > 1) {
+        out = g.slab + ((long)ks * g.batch + bz) * g.M * g.N;
+        ld = g.N;
+    } else {
+        out = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
+        ld = g.ldc;
+    }
+    const bool acc_c = g.splitk == 1 && g.accumulate;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float* c = out + (long)row * ld + col;
+                *c = acc_c ? *c + acc[i][j][r] : acc[i][j][r];
+            }
+    }
+}
+
+// C (+)= sum over the k-slabs in slab order; the tail of the grid sums the bias-gradient slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradK g) {
+    const long per4 = (long)g.M * g.N / 4;
+    const long total4 = (long)g.batch * per4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total4) {
+        const float4* s4 = reinterpret_cast<const float4*>(g.slab) + idx;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int k = 0; k < g.splitk; ++k) {
+            const float4 v = s4[(long)k * total4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long bz = idx / per4, rem = (idx - bz * per4) * 4;
+        const long row = rem / g.N;
+        const int col = (int)(rem - row * g.N);
+        float* c = g.C + (g.c_off ? g.c_off[bz] : bz * g.c_batch) + row * g.ldc + col;
+        if (g.c_vec) {
+            float4* c4 = reinterpret_cast<float4*>(c);
+            if (g.accumulate) {
+                const float4 o = *c4;
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *c4 = s;
+        } else {
+            if (g.accumulate) { s.x += c[0]; s.y += c[1]; s.z += c[2]; s.w += c[3]; }
+            c[0] = s.x; c[1] = s.y; c[2] = s.z; c[3] = s.w;
+        }
+        return;
+    }
+    const long e = idx - total4;
+    if (g.colsum == nullptr || e >= (long)g.batch * g.M) return;
+    float s = 0.f;
+    for (int k = 0; k < g.splitk; ++k) s += g.cs_slab[(long)k * g.batch * g.M + e];
+    const long bz = e / g.M;
+    g.colsum[bz * g.colsum_batch + (e - bz * g.M)] = s;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Takes the GEMM if it is a weight-gradient shape this kernel is built for (returns 1 and launches), else returns 0;
+// negative = error.  Called by as_gemm_f32 ahead of its general tile selection.
+int as_wgrad_try(const as_gemm* g, hipStream_t st) {
+    static const bool off = getenv("AS_NO_WGRAD") != nullptr;  // ablation: the general kernel
+    if (off) return 0;
+    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % BK || g->b_kT > 0 || g->act != 0 || g->bias) return 0;
+    if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return 0;
+    const bool grouped = g->a_off || g->b_off || g->c_off;
+    if (!grouped && (g->a_batch % 4 || g->b_batch % 4)) return 0;
+    if ((long)g->M * g->N % 4) return 0;
+    WgradK k{};
+    k.A = g->A; k.B = g->B; k.C = g->C;
+    k.M = g->M; k.N = g->N; k.K = g->K;
+    k.lda = g->a_k; k.ldb = g->b_k; k.ldc = g->ldc;
+    k.a_batch = g->a_batch; k.b_batch = g->b_batch; k.c_batch = g->c_batch;
+    k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
+    k.batch = g->batch;
+    k.b_kshift = g->b_kshift; k.b_kT = g->b_kT; k.b_kshift_batch = g->b_kshift_batch;
+    k.accumulate = g->accumulate;
+    k.c_vec = aligned16(g->C) && g->ldc % 4 == 0 && (g->c_off ? 1 : g->c_batch % 4 == 0);
+    k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
+    static const int abl = getenv("AS_WGRAD_ABL") ? atoi(getenv("AS_WGRAD_ABL")) : 0;
+    k.abl = abl;
+    const int bn = g->N > 128 ? 256 : 128;
+    k.tiles_m = as_cdiv(g->M, BM);
+    k.tiles_n = as_cdiv(g->N, bn);
+    const long tiles = (long)k.tiles_m * k.tiles_n * g->batch;
+    static const bool all_shapes = getenv("AS_WGRAD_ALL") != nullptr;  // tuning aid: also the shapes below
+    // too little work to give every CU a 128-row tile over >= 256 frames: the general kernel's 64 x 64 tiles spread it better
+    if (!all_shapes && tiles * (g->K / 256) < 256) return 0;
+    // split K so that the launch has about `target` workgroups (one per CU and round); cost model in DESIGN.md 5
+    static const int target_env = getenv("AS_WGRAD_TARGET") ? atoi(getenv("AS_WGRAD_TARGET")) : 0;
+    const int cus = g->cu_budget > 0 ? g->cu_budget : 256;
+    long S = 1;
+    const long per = (long)g->batch * g->M * g->N, per_cs = g->colsum ? (long)g->batch * g->M : 0;
+    if (g->splitk_ws && tiles < cus) {
+        if (target_env > 0) {
+            S = target_env / tiles;
+        } else {
+            // time ~ rounds * k-steps per workgroup * c1 + slab traffic; c1 = us per k of one 128 x bn tile on one CU
+            const double c1 = (bn == 256 ? 256.0 : 128.0) / 2400.0, c2 = 8.0 / 4.0e6;  // write + read of a float at ~4 TB/s
+            double best = 1e30;
+            for (long s = 1; s <= 64 && s * 128 <= g->K; ++s) {
+                const long chunk = as_round_up(as_cdiv(g->K, s), BK);
+                const long rounds = (tiles * s + cus - 1) / cus;
+                const double cost = rounds * chunk * c1 + (s > 1 ? s * (per + per_cs) * c2 : 0.0);
+                if (cost < best - 1e-9) best = cost, S = s;
+            }
+        }
+        if (S > g->K / 128) S = g->K / 128;
+        if (S * (per + per_cs) > g->splitk_ws_floats) S = g->splitk_ws_floats / (per + per_cs);
+        if (S < 1) S = 1;
+    }
+    k.kchunk = (int)as_round_up(as_cdiv(g->K, S), BK);
+    k.splitk = as_cdiv(g->K, k.kchunk);
+    if (k.splitk > 1) {
+        k.slab = g->splitk_ws;
+        k.cs_slab = g->splitk_ws + (long)k.splitk * per;
+    }
+    k.ncombos = (long)g->batch * k.splitk * k.tiles_n;
+    k.per_xcd = (int)((k.ncombos * k.tiles_m + 7) / 8);
+    const dim3 grid((unsigned)(8 * k.per_xcd));
+    if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256>), grid, dim3(NT), 0, st, k);
+    else hipLaunchKernelGGL((wgrad_f32_kernel<128>), grid, dim3(NT), 0, st, k);
+    AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
+    if (k.splitk > 1) {
+        const long threads = per / 4 + per_cs;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
+        AS_LAUNCH_CHECK("as_gemm_f32(wgrad reduce)");
+    }
+    return 1;
+}

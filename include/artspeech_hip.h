@@ -177,6 +177,10 @@ typedef struct as_gemm {
        cross terms with fp32 accumulation (error ~2^-16 / ~2^-23 of sum |a||b|); other shapes silently stay exact. */
     int32_t precision;
     int32_t b_kshift_batch;
+    /* optional hint for weight-gradient shapes (a_i == b_j == 1 with splitk_ws): the number of CUs the launch can expect to
+       have (0 = the whole chip), e.g. 192 while a 64-workgroup recurrence kernel runs beside it on another stream; only the
+       split-K factor depends on it, never the result's summation order for a given factor. */
+    int32_t cu_budget;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 
