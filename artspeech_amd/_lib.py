@@ -70,6 +70,7 @@ PROTOTYPES = {
     "as_euclid_masked_fwd_bwd_presigmoid": (_I32, [_P, _P, _I64, _P, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P]),
     "as_p2cp_fwd": (_I32, [_P, _I64, _I64, _I64, _I32, _P, _I64, _I64, _I64, _I32, _I64, _P, _P]),
     "as_p2cp_utterance_mean": (_I32, [_P, _P, _I32, _I32, _I32, _F, _P, _P]),
+    "as_pearson_fwd": (_I32, [_P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "as_tract_variables_fwd": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "as_area_function_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _D, _D, _P, _P, _P]),
     "as_evenly_spaced_fx": (_I32, [_P, _P, _I64, _I32, _I32, _P, _P]),
@@ -99,7 +100,7 @@ PROTOTYPES = {
     "as_lstm_bidir_bwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_gru_unidir_fwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_intersect_semipolar_grid": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
-    "as_artspeech_wait_head_grads": (_I32, [_P]),
+    "as_artspeech_wait_head_grads": (_I32, [_P, _P]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),
     "as_profile_report": (_I32, [C.c_char_p, _I32]),

@@ -15,6 +15,9 @@
 //    writes sigmoid(.) straight into the (B, T, A, 2, N) output (:141-145).
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "rowops.h"
 
 namespace {
@@ -95,6 +98,8 @@ ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
     } else {
         w.tab0 = c.take(V * H);   // relu(Emb Wl^T + bl) per token
         w.dtab0 = c.take(V * H);
+        w.y0 = c.take(R * d.embed);   // training with dropout p > 0: the embedded frames after dropout ...
+        w.dy0 = c.take(R * d.embed);  // ... and the gradient that reaches them
     }
     w.lin = c.take(R * H);
     w.head = c.take(head_ws(d, R).total);
@@ -223,44 +228,69 @@ int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t ro
     return 0;
 }
 
-// ---- library-owned side stream: weight-gradient GEMMs (throughput bound, fill the chip) run beside the
-// GRU backward recurrences (latency bound, 2*B workgroups) instead of after them.  Fork/join are
-// stream-ordered event waits: no host synchronisation, capturable in a HIP graph.
-struct Side {
-    hipStream_t s = nullptr;
+// ---- per-(device, caller stream) state: a library-owned side stream + fork/join events, and the "head gradients are
+// final" event.  Weight-gradient GEMMs (throughput bound, fill the chip) run on the side stream beside the GRU backward
+// recurrences (latency bound, 2*B workgroups) instead of after them.  Fork/join are stream-ordered event waits: no host
+// synchronisation, capturable in a HIP graph.  Keyed by the CALLER'S stream, so two models (or two host threads) that
+// drive the library on different streams of one device never share a side stream or an event; calls on ONE stream are
+// ordered by that stream anyway.
+struct StreamState {
+    int dev = -1;
+    hipStream_t owner = nullptr;
+    hipStream_t side = nullptr;                                   // created on first use with overlap on
     hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
-    bool ok = false;
+    hipEvent_t heads = nullptr;                                   // recorded by as_artspeech_bwd
 };
 int g_overlap = -1;  // -1: not decided yet (environment), 0: off, 1: on
-Side* side_for_current_device() {
-    static Side sides[16];
+std::mutex g_state_mu;
+std::vector<StreamState*> g_states;
+
+StreamState* state_for(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_state_mu);
+    for (StreamState* p : g_states)
+        if (p->dev == dev && p->owner == st) return p;
+    if (g_states.size() >= 256) return nullptr;
+    // nothing may be created inside a stream capture: the caller warms the library up once before capturing
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    StreamState* p = new StreamState;
+    p->dev = dev;
+    p->owner = st;
+    bool ok = hipEventCreateWithFlags(&p->heads, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->join, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : p->fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        delete p;
+        return nullptr;
+    }
+    g_states.push_back(p);
+    return p;
+}
+// the side stream of the caller's stream, or nullptr when overlap is off / unavailable
+StreamState* side_for(hipStream_t st) {
     if (g_overlap < 0) g_overlap = getenv("ARTSPEECH_NO_OVERLAP") ? 0 : 1;
     if (!g_overlap) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Side& sd = sides[dev];
-    if (!sd.ok) {
-        if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (auto& e : sd.fork)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        sd.ok = true;
+    StreamState* p = state_for(st);
+    if (!p) return nullptr;
+    if (!p->side) {
+        std::lock_guard<std::mutex> lock(g_state_mu);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+        if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
+            p->side = nullptr;
+            return nullptr;
+        }
     }
-    return &sd;
+    return p;
 }
 // "gradients of the trunk Linear and of all heads are final" -- recorded by as_artspeech_bwd on the stream that produced
 // them, so that a data-parallel host can start their all-reduce while the GRU backward is still running.
-hipEvent_t heads_event_for_current_device() {
-    static hipEvent_t ev[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
-    return ev[dev];
-}
-int record_heads_done(hipStream_t s) {
-    hipEvent_t ev = heads_event_for_current_device();
-    AS_REQUIRE(ev, AS_ERR_UNSUPPORTED, "as_artspeech_bwd: no event for this device");
-    const hipError_t e = hipEventRecord(ev, s);
+int record_heads_done(hipStream_t owner, hipStream_t s) {
+    StreamState* p = state_for(owner);
+    AS_REQUIRE(p, AS_ERR_UNSUPPORTED, "as_artspeech_bwd: no per-stream state (first call inside a stream capture?)");
+    const hipError_t e = hipEventRecord(p->heads, s);
     AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_bwd: hipEventRecord failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -279,10 +309,10 @@ int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
 
 extern "C" void as_set_overlap(int32_t on) { g_overlap = on ? 1 : 0; }
 
-extern "C" int as_artspeech_wait_head_grads(void* stream) {
-    hipEvent_t ev = heads_event_for_current_device();
-    AS_REQUIRE(ev, AS_ERR_UNSUPPORTED, "as_artspeech_wait_head_grads: no event for this device");
-    const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+extern "C" int as_artspeech_wait_head_grads(void* compute_stream, void* waiting_stream) {
+    StreamState* p = state_for((hipStream_t)compute_stream);
+    AS_REQUIRE(p, AS_ERR_UNSUPPORTED, "as_artspeech_wait_head_grads: as_artspeech_bwd has not run on that stream");
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)waiting_stream, p->heads, 0);
     AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_wait_head_grads: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -360,7 +390,6 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(check_dims(d, "as_artspeech_fwd"));
     const float pdrop = (opts && train) ? opts->gru_dropout : 0.f;
     AS_REQUIRE(pdrop >= 0.f && pdrop < 1.f, AS_ERR_BAD_ARG, "as_artspeech_fwd: dropout %g not in [0, 1)", (double)pdrop);
-    AS_REQUIRE(!(pdrop > 0.f && d->simple), AS_ERR_UNSUPPORTED, "as_artspeech_fwd: dropout is built for the GRU model only");
     AS_REQUIRE(P && tokens && out && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG, "as_artspeech_fwd: bad argument");
     AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_fwd: lengths required for the GRU model");
     AS_REQUIRE((int64_t)B * T < (1LL << 31), AS_ERR_BAD_ARG, "as_artspeech_fwd: B*T too large");
@@ -370,11 +399,11 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     const ModelWs w = model_ws(*d, B, T);
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
     // the weight folds depend on the parameters only: run them on the side stream beside the recurrences
-    Side* sd = d->simple ? nullptr : side_for_current_device();
+    StreamState* sd = d->simple ? nullptr : side_for(st);
     if (sd) {
-        AS_TRY(fork_to(st, sd->s, sd->fork[0]));
-        AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->s));
-        if (hipEventRecord(sd->join, sd->s) != hipSuccess) {
+        AS_TRY(fork_to(st, sd->side, sd->fork[0]));
+        AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->side));
+        if (hipEventRecord(sd->join, sd->side) != hipSuccess) {
             as_set_error("as_artspeech_fwd: event record failed");
             return AS_ERR_BAD_ARG;
         }
@@ -395,6 +424,12 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
                                 train ? ws + w.g1 : nullptr, st));
         AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
+    } else if (pdrop > 0.f) {
+        // SimpleArtSpeech in training mode (models.py:64,85): Dropout acts on the embedded frame, so every position has its
+        // own mask and the token-table fold below does not apply: gather -> counter mask -> Linear + ReLU on all frames
+        AS_TRY(as_gather_rows(P + L.embedding, tokens, tok_stride, T, R, E, ws + w.y0, st));
+        AS_TRY(as_dropout(ws + w.y0, ws + w.y0, (long)R * E, pdrop, opts->dropout_seed, st));
+        AS_TRY(gemm_nt(ws + w.y0, E, P + L.lin_w, E, ws + w.lin, H, P + L.lin_b, R, H, E, 1, st));
     } else {
         AS_TRY(gemm_nt(P + L.embedding, E, P + L.lin_w, E, ws + w.tab0, H, P + L.lin_b, V, H, E, 1, st));
         AS_TRY(as_gather_rows(ws + w.tab0, tokens, tok_stride, T, R, H, ws + w.lin, st));
@@ -411,7 +446,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
                                 float* ws, const as_opts* opts, void* stream) {
     AS_TRY(check_dims(d, "as_artspeech_bwd"));
     const float pdrop = opts ? opts->gru_dropout : 0.f;
-    AS_REQUIRE(pdrop >= 0.f && pdrop < 1.f && !(pdrop > 0.f && d->simple), AS_ERR_BAD_ARG, "as_artspeech_bwd: bad dropout option");
+    AS_REQUIRE(pdrop >= 0.f && pdrop < 1.f, AS_ERR_BAD_ARG, "as_artspeech_bwd: bad dropout option");
     AS_REQUIRE(P && tokens && out && dout && G && ws && B > 0 && T > 0 && tok_stride >= T, AS_ERR_BAD_ARG,
                "as_artspeech_bwd: bad argument");
     AS_REQUIRE(d->simple || lengths, AS_ERR_BAD_ARG, "as_artspeech_bwd: lengths required for the GRU model");
@@ -431,15 +466,22 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st, presig));
     if (d->simple) {
         AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st, dpre3));
-        AS_TRY(record_heads_done(st));
+        AS_TRY(record_heads_done(st, st));
+        if (pdrop > 0.f) {  // per-frame path of the forward: Linear backward on all frames, mask regenerated from the seed
+            AS_TRY(gemm_tn(dzlin, H, ws + w.y0, E, G + L.lin_w, E, H, E, R, st, slab, G + L.lin_b, 0));
+            AS_TRY(gemm_nn(dzlin, H, P + L.lin_w, E, ws + w.dy0, E, R, E, H, st));
+            AS_TRY(as_dropout(ws + w.dy0, ws + w.dy0, (long)R * E, pdrop, opts->dropout_seed, st));
+            AS_TRY(as_token_segsum(ws + w.dy0, tokens, tok_stride, T, R, E, V, G + L.embedding, st, slab, SLAB_FLOATS));
+            return 0;
+        }
         // lin = gather(relu(Emb Wl^T + bl)); dzlin already carries the ReLU mask of the gathered rows
         AS_TRY(as_token_segsum(dzlin, tokens, tok_stride, T, R, H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
         AS_TRY(gemm_tn(ws + w.dtab0, H, P + L.embedding, E, G + L.lin_w, E, H, E, V, st, slab, G + L.lin_b, 0));
         AS_TRY(gemm_nn(ws + w.dtab0, H, P + L.lin_w, E, G + L.embedding, E, V, E, H, st));
         return 0;
     }
-    Side* sd = side_for_current_device();
-    hipStream_t s2 = sd ? sd->s : st;      // no side stream: everything in order on `st`
+    StreamState* sd = side_for(st);
+    hipStream_t s2 = sd ? sd->side : st;      // no side stream: everything in order on `st`
     float* sl2 = sd ? slab2 : slab;
     AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
@@ -448,7 +490,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     const int side_cus = sd ? 192 : 0;  // the recurrence's 2 * B workgroups hold 64 CUs while the side stream works
     AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
-    AS_TRY(record_heads_done(s2));  // [lin_w, total) of the flat gradient buffer is final from here on
+    AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
     if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));

@@ -409,6 +409,41 @@ inline int ew_grid(long n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+
+// ---------------------------------------------------------------- Pearson correlation over time (root metrics.py:9-35)
+// One thread per (utterance, articulator, plane, point) column; consecutive threads read consecutive floats of a frame's
+// [A][2][N] block, so every pass over T is coalesced.  Two passes: means, then centred sums (double accumulators).
+// The x plane's TARGETS are centred with the x OUTPUTS' mean, as the reference does (metrics.py:22); y with its own (:30).
+__global__ __launch_bounds__(256) void pearson_kernel(const float* __restrict__ out, long out_b, long out_t,
+                                                      const float* __restrict__ tgt, long tgt_b, long tgt_t, int B, int T,
+                                                      int A, int N, float eps, float* __restrict__ x_corr,
+                                                      float* __restrict__ y_corr) {
+    const long cols = (long)A * 2 * N;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * cols) return;
+    const long b = idx / cols;
+    const int c = (int)(idx - b * cols);
+    const int a = c / (2 * N), plane = (c / N) & 1, n = c % N;
+    const float* o = out + b * out_b + c;
+    const float* g = tgt + b * tgt_b + c;
+    double so = 0.0, sg = 0.0;
+    for (int t = 0; t < T; ++t) {
+        so += (double)o[(long)t * out_t];
+        sg += (double)g[(long)t * tgt_t];
+    }
+    const float mo = (float)(so / T);
+    const float mg = plane == 0 ? mo : (float)(sg / T);
+    double sog = 0.0, soo = 0.0, sgg = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const float vo = o[(long)t * out_t] - mo, vg = g[(long)t * tgt_t] - mg;
+        sog += (double)vo * vg;
+        soo += (double)vo * vo;
+        sgg += (double)vg * vg;
+    }
+    const float r = (float)sog / (sqrtf((float)soo) * sqrtf((float)sgg) + eps);
+    (plane == 0 ? x_corr : y_corr)[(b * A + a) * N + n] = r;
+}
+
 }  // namespace
 
 extern "C" int as_euclid_fwd(const float* out, const float* tgt, int64_t frames, int32_t A, int32_t N, float* dist,
@@ -476,6 +511,16 @@ extern "C" int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t
     hipLaunchKernelGGL(p2cp_kernel, dim3(as_cdiv(tiles, 4)), dim3(256), shm, (hipStream_t)stream, u, (long)u_tile, (long)u_pt,
                        (long)u_xy, n_u, v, (long)v_tile, (long)v_pt, (long)v_xy, n_v, (long)tiles, out);
     AS_LAUNCH_CHECK("as_p2cp_fwd");
+    return 0;
+}
+
+extern "C" int as_pearson_fwd(const float* out, int64_t out_b, int64_t out_t, const float* tgt, int64_t tgt_b, int64_t tgt_t,
+                              int32_t B, int32_t T, int32_t A, int32_t N, float eps, float* x_corr, float* y_corr, void* stream) {
+    AS_REQUIRE(out && tgt && x_corr && y_corr && B > 0 && T > 0 && A > 0 && N > 0, AS_ERR_BAD_ARG, "as_pearson_fwd: bad argument");
+    const long total = (long)B * A * 2 * N;
+    hipLaunchKernelGGL(pearson_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)out_b, (long)out_t,
+                       tgt, (long)tgt_b, (long)tgt_t, B, T, A, N, eps, x_corr, y_corr);
+    AS_LAUNCH_CHECK("as_pearson_fwd");
     return 0;
 }
 

@@ -77,7 +77,7 @@ class TrainStep:
         if not self.ar_overlap:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
             return
-        _lib.check(_lib.lib().as_artspeech_wait_head_grads(self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
+        _lib.check(_lib.lib().as_artspeech_wait_head_grads(_lib.stream_ptr(), self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
         with torch.cuda.stream(self.comm_stream):
             tail = dist.all_reduce(self.grads[self.head_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         head = dist.all_reduce(self.grads[:self.head_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

@@ -132,9 +132,12 @@ class DeepSpeech2(nn.Module):
 
     # ------------------------------------------------------------------ weights in kernel order (cached per version)
     def _prepare(self):
+        # (address, version) of every parameter; the entry also holds the parameters' storages, so none of those
+        # addresses can be freed and handed to a different tensor while the entry is alive
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._prepared is not None and self._prepared[0] == key:
             return self._prepared[1]
+        keep = [p.untyped_storage() for p in self.parameters()]
         with torch.no_grad():
             taps = lambda conv: conv.weight.permute(2, 3, 0, 1).contiguous()  # [kd][kt][co][ci]
             D = self.num_features
@@ -142,7 +145,7 @@ class DeepSpeech2(nn.Module):
                      res=[(taps(r.cnn1), taps(r.cnn2)) for r in self.residual_layers],
                      # column c*D + d of the reference's (B, C*D, T) view -> column d*32 + c of a channels-last frame row
                      linear=self.linear.weight.view(self.hidden, OUT_CHANNELS, D).permute(0, 2, 1).reshape(self.hidden, -1).contiguous())
-        self._prepared = (key, w)
+        self._prepared = (key, w, keep)
         return w
 
     def forward(self, x, voicing=None, return_features=False):

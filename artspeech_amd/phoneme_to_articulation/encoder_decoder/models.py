@@ -231,12 +231,15 @@ class SimpleArtSpeech(_FlatModule):
         self._setup(dims, _reference_init(vocab_size, n_articulators, embed_dim, hidden_size, num_samples, simple=True))
 
     def forward(self, x, lengths=None):
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("SimpleArtSpeech: dropout > 0 in training mode is not built yet")
         _lib.require_gpu(x, "x")
         _lib.require_gpu(self.flat, "model parameters")
         if x.dtype != torch.int64:
             x = x.long()
         if x.stride(1) != 1:
             x = x.contiguous()
-        return _ArtSpeechFn.apply(self.flat, x, None, self.dims, x.shape[0], x.shape[1])
+        opts = None
+        if self.training and self.dropout > 0.0:
+            # nn.Dropout on the embedded frames (reference models.py:64,85): per-position counter mask, seed drawn from
+            # torch's CPU generator like the GRU model's inter-layer dropout
+            opts = _lib.Opts(self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return _ArtSpeechFn.apply(self.flat, x, None, self.dims, x.shape[0], x.shape[1], opts)

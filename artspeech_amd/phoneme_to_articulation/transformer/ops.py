@@ -8,6 +8,7 @@ channel ``src[g]`` of a channel-major input ``[C][rows][K]``.
 import ctypes as C
 import math
 import os
+import weakref
 
 import torch
 
@@ -196,24 +197,24 @@ class GroupedLinear(torch.autograd.Function):
 
 FUSED_DS = os.environ.get("ARTSPEECH_UNFUSED_DS") is None  # ablation: dP GEMM + as_attn_softmax_bwd_t instead of as_attention_bwd_ds
 FUSED_ATTENTION = os.environ.get("ARTSPEECH_UNFUSED_ATTENTION") is None  # ablation switch (tools/bench_attention.py)
-_MASK_T = {}
+_MASK_T = {}  # id(mask tensor) -> (weak reference to it, (version, Tk, T), key-major copy)
 
 
 def _key_major_mask(attn_mask, Tk, T):
     """(B, T, Tk) additive mask -> (B, Tk32, T): key-major, keys zero-padded to a multiple of 32 (as_attention_fwd).
-    The same mask tensor serves every attention call of a forward pass: the last few transposes are kept."""
-    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), attn_mask.device)
-    hit = _MASK_T.get(key)
-    if hit is None:
-        B = attn_mask.shape[0]
-        mt = torch.zeros((B, (Tk + 31) // 32 * 32, T), dtype=torch.float32, device=attn_mask.device)
-        mt[:, :Tk] = attn_mask.to(torch.float32).transpose(1, 2)
-        if len(_MASK_T) >= 4:
-            _MASK_T.pop(next(iter(_MASK_T)))
-        # the entry keeps the SOURCE tensor alive: its storage cannot be freed and handed to another mask with the same
-        # address, shape and version while the key is in the cache
-        hit = _MASK_T[key] = (attn_mask, mt)
-    return hit[1]
+    The same mask tensor serves every attention call of a forward pass, so the transpose is kept -- keyed on the tensor
+    OBJECT (weak reference + version counter), never on its address: a mask that has been freed takes its entry with it,
+    and a new mask that happens to get the same storage address (or the same id) can never hit a stale entry."""
+    k = id(attn_mask)
+    tag = (attn_mask._version, Tk, T)
+    hit = _MASK_T.get(k)
+    if hit is not None and hit[0]() is attn_mask and hit[1] == tag:
+        return hit[2]
+    B = attn_mask.shape[0]
+    mt = torch.zeros((B, (Tk + 31) // 32 * 32, T), dtype=torch.float32, device=attn_mask.device)
+    mt[:, :Tk] = attn_mask.to(torch.float32).transpose(1, 2)
+    _MASK_T[k] = (weakref.ref(attn_mask, lambda _r, k=k: _MASK_T.pop(k, None)), tag, mt)
+    return mt
 
 
 class Attention(torch.autograd.Function):

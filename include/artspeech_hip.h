@@ -79,7 +79,8 @@ int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T)
  * to the layer-0 output in training mode only).  The mask is a pure function of (dropout_seed, element): pass the
  * SAME options to the matching as_artspeech_bwd.  Statistical, not bitwise, parity with torch's generator. */
 typedef struct as_opts {
-    float gru_dropout;      /* 0 <= p < 1 */
+    float gru_dropout;      /* 0 <= p < 1: nn.GRU inter-layer dropout (ArtSpeech, models.py:111) or, with dims->simple, the
+                               nn.Dropout on the embedded frames of SimpleArtSpeech (models.py:64,85) */
     uint64_t dropout_seed;
     /* as_artspeech_bwd only: non-zero => `dout` already holds the gradient w.r.t. the PRE-sigmoid activations (written by
        as_euclid_masked_fwd_bwd_presigmoid), so the separate dout * out * (1 - out) pass over the contours is skipped. */
@@ -105,13 +106,16 @@ int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* to
 
 /* as_artspeech_bwd runs the weight-gradient GEMMs on a library-owned side stream beside the GRU backward
  * recurrences (fork/join by stream-ordered events; `stream` observes completion of everything on return
- * order).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
+ * order).  The side stream and its events belong to the (device, `stream`) pair: callers on different streams never
+ * share them.  They are created on the first call for that pair, never inside a stream capture (run one step before
+ * capturing).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
 void as_set_overlap(int32_t on);
 
-/* Data-parallel hook: make `stream` wait until the most recent as_artspeech_bwd on the current device has finished the
- * gradients of the trunk Linear and of all heads, i.e. the tail [layout.lin_w, layout.total) of the flat gradient buffer
- * (74 % of the parameters) -- their all-reduce can then run while the GRU backward recurrences are still going. */
-int as_artspeech_wait_head_grads(void* stream);
+/* Data-parallel hook: make `waiting_stream` wait until the most recent as_artspeech_bwd enqueued on `compute_stream` (same
+ * device) has finished the gradients of the trunk Linear and of all heads, i.e. the tail [layout.lin_w, layout.total) of
+ * the flat gradient buffer (74 % of the parameters) -- their all-reduce can then run while the GRU backward recurrences
+ * are still going. */
+int as_artspeech_wait_head_grads(void* compute_stream, void* waiting_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Building blocks (each is also used by the composite entry points above)
@@ -229,6 +233,14 @@ int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t u_xy, int3
  * result[0] = mean_b( mean_{t < len_b, a} p2cp * to_mm ). */
 int as_p2cp_utterance_mean(const float* p2cp, const int32_t* lengths, int32_t B, int32_t T, int32_t A, float to_mm,
                            float* result, void* stream);
+
+/* pearsons_correlation (root metrics.py:9-35): Pearson correlation over time of every (utterance, articulator, point)
+ * column, x and y planes separately.  out / tgt: [B][T][A][2][N] with element strides out_b / out_t (tgt_b / tgt_t)
+ * for the utterance and frame index, the [A][2][N] block of a frame contiguous.  x_corr, y_corr: [B][A][N].
+ * corr = sum(vo * vt) / (sqrt(sum vo^2) * sqrt(sum vt^2) + eps); as in the reference the x TARGETS are centred with
+ * the x OUTPUTS' mean (metrics.py:22), the y targets with their own (metrics.py:30). */
+int as_pearson_fwd(const float* out, int64_t out_b, int64_t out_t, const float* tgt, int64_t tgt_b, int64_t tgt_t,
+                   int32_t B, int32_t T, int32_t A, int32_t N, float eps, float* x_corr, float* y_corr, void* stream);
 
 /* Tract variables (tract_variables.py:23-35, 73-125): for each frame and each of n_tv variables the
  * minimum pairwise distance between two point sets and the two closest points (first minimum over

@@ -251,25 +251,31 @@ def artspeech_bwd(dout, cache, n_art):
     return grads
 
 
-def simple_artspeech_fwd(params, x, n_art, dtype=np.float64):
-    """SimpleArtSpeech.forward (models.py:75-96), dropout 0; ignores lengths."""
+def simple_artspeech_fwd(params, x, n_art, dtype=np.float64, embed_scale=None):
+    """SimpleArtSpeech.forward (models.py:75-96); ignores lengths.  embed_scale: optional (B, T, E) array that multiplies the
+    embedded frames -- the nn.Dropout of models.py:64,85 in training mode, given its mask (0 or 1 / (1 - p))."""
     p = _cast(params, dtype)
     emb = p["embedding.weight"][np.asarray(x)]
+    if embed_scale is not None:
+        emb = emb * np.asarray(embed_scale, dtype)
     zlin = emb @ p["linear.0.weight"].T + p["linear.0.bias"]
     lin = np.maximum(zlin, 0.0)
     out, head_caches = heads_fwd(lin, p, n_art)
-    return out, (p, np.asarray(x), emb, zlin, head_caches, out)
+    return out, (p, np.asarray(x), emb, zlin, head_caches, out, embed_scale)
 
 
 def simple_artspeech_bwd(dout, cache, n_art):
-    p, x, emb, zlin, head_caches, out = cache
+    p, x, emb, zlin, head_caches, out, embed_scale = cache
     dlin, grads = heads_bwd(dout, out, head_caches, p, n_art)
     dz = dlin * (zlin > 0)
     F = lambda t: t.reshape(-1, t.shape[-1])  # noqa: E731
     grads["linear.0.weight"] = F(dz).T @ F(emb)
     grads["linear.0.bias"] = F(dz).sum(0)
+    demb_frames = dz @ p["linear.0.weight"]
+    if embed_scale is not None:
+        demb_frames = demb_frames * np.asarray(embed_scale, demb_frames.dtype)
     demb = np.zeros_like(p["embedding.weight"])
-    np.add.at(demb, x.reshape(-1), F(dz @ p["linear.0.weight"]))
+    np.add.at(demb, x.reshape(-1), F(demb_frames))
     grads["embedding.weight"] = demb
     return grads
 

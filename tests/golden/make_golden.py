@@ -431,7 +431,121 @@ def gen_pc_autoencoder(ae, losses):
             "pc_critical_loss": dict(loss=float(loss))}
 
 
+# ----------------------------------------------------------------------------- test / training loops
+TV_ARTS = sorted(["lower-lip", "pharynx", "soft-palate-midline", "tongue", "upper-lip"])  # + injected upper incisor
+
+
+class _CapturedLoader:
+    """A DataLoader stand-in: fixed list of collated batches + `.dataset.dataset_config` (evaluation.py:35)."""
+
+    def __init__(self, batches, dataset_config):
+        self.batches = batches
+        self.dataset = types.SimpleNamespace(dataset_config=dataset_config)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def gen_test_loops(models, dataset, p2a_metrics, ed_metrics, settings, ref_eval, ref_train):
+    """The reference's own harnesses on a captured 6-utterance loader (2 batches of 3):
+      * run_epoch(TRAIN) with SGD (train_phoneme_to_articulation.py:45-121)  -> info + the parameters it leaves,
+      * run_epoch(VALID) with fn_metrics = {p2cp_mean: P2CPDistance}        -> info,
+      * run_test (encoder_decoder/evaluation.py:17-161, regularize_out=False) -> info dict, tract_variables.csv, contour dumps.
+    SGD instead of the trainer's Adam: an Adam step is ~lr * sign(g) for every element, so parameters whose gradient is
+    rounding noise differ by 2 * lr between two correct fp32 implementations; with SGD the update is proportional to the
+    gradient and the comparison is meaningful."""
+    import csv
+    import tempfile
+    torch.manual_seed(21)
+    V, A, E, H, N = 20, len(TV_ARTS), 32, 64, 50
+    lens = [13, 9, 11, 4, 17, 1]
+    items = []
+    for i, l in enumerate(lens):
+        items.append((
+            f"sent{i}", torch.randint(2, V, (l,)), torch.rand(l, A, 2, N), [f"ph{int(t)}" for t in torch.randint(0, 9, (l,))],
+            torch.rand(l, 1, 2, N), torch.tensor([], dtype=torch.int), [f"{1000 * i + j:04d}" for j in range(l)],
+            (torch.rand(l) > 0.5).float(),
+        ))
+    batches = [dataset.pad_sequence_collate_fn(items[:3]), dataset.pad_sequence_collate_fn(items[3:])]
+    cfg = settings.DATASET_CONFIG["artspeech2"]
+    loader = _CapturedLoader(batches, cfg)
+    model = models.ArtSpeech(V, A, embed_dim=E, hidden_size=H, n_samples=N)
+    w0 = {k: v.copy() for k, v in sd_to_np("w0.", model.state_dict()).items()}  # copies: SGD updates the parameters in place
+    crit = p2a_metrics.EuclideanDistance("none")
+    cpu = torch.device("cpu")
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    train_info = ref_train.run_epoch(settings.TRAIN, 1, model, loader, opt, crit, device=cpu)
+    w1 = sd_to_np("w1.", model.state_dict())
+    valid_info = ref_train.run_epoch(settings.VALID, 1, model, loader, opt, crit,
+                                     fn_metrics={"p2cp_mean": ed_metrics.P2CPDistance(cfg)}, device=cpu)
+    with tempfile.TemporaryDirectory() as d:
+        test_info = ref_eval.run_test(7, model, loader, crit, d, TV_ARTS, device=cpu, regularize_out=False)
+        sdir = os.path.join(d, "7", "sent4")
+        with open(os.path.join(sdir, "tract_variables.csv")) as f:
+            rows = list(csv.reader(f))
+        tv_cols, tv_rows = rows[0], rows[1:]
+        with open(os.path.join(sdir, "phonemes.csv")) as f:
+            ph_rows = list(csv.reader(f))
+        contour_files = sorted(os.listdir(os.path.join(sdir, "contours")))
+        frame0 = items[4][6][0]
+        pred_tongue = np.load(os.path.join(sdir, "contours", f"{frame0}_tongue.npy"))
+        true_incisor = np.load(os.path.join(sdir, "contours", f"{frame0}_upper-incisor_true.npy"))
+        n_dirs = len(os.listdir(os.path.join(d, "7")))
+    num = [c for c in tv_cols if c not in ("sentence", "frame", "phoneme")]
+    arrays = dict(
+        cfg=np.array([V, A, E, H, N], dtype=np.int64), articulators=np.array(TV_ARTS), lens=np.array(lens),
+        train_loss=np.float64(train_info["loss"]), valid_loss=np.float64(valid_info["loss"]),
+        valid_p2cp_mean=np.float64(valid_info["p2cp_mean"]), test_loss=np.float64(test_info["loss"]),
+        test_metric_names=np.array(["x_corr", "y_corr", "p2cp", "p2cp_mm", "med", "med_mm"]),
+        test_metrics=np.array([[test_info[a][k] for k in ("x_corr", "y_corr", "p2cp", "p2cp_mm", "med", "med_mm")] for a in TV_ARTS],
+                              dtype=np.float64),
+        tv_columns=np.array(tv_cols), tv_numeric_columns=np.array(num),
+        tv_values=np.array([[float(r[tv_cols.index(c)]) for c in num] for r in tv_rows], dtype=np.float64),
+        tv_frames=np.array([r[tv_cols.index("frame")] for r in tv_rows]),
+        tv_phonemes=np.array([r[tv_cols.index("phoneme")] for r in tv_rows]),
+        phonemes_csv=np.array(ph_rows), contour_files=np.array(contour_files), n_sentence_dirs=np.int64(n_dirs),
+        pred_tongue_frame0=pred_tongue, true_incisor_frame0=true_incisor,
+    )
+    for i, it in enumerate(items):
+        arrays[f"in{i}_id"] = np.array(it[0])
+        arrays[f"in{i}_tokens"], arrays[f"in{i}_targets"], arrays[f"in{i}_refs"] = it[1].numpy(), it[2].numpy(), it[4].numpy()
+        arrays[f"in{i}_phonemes"], arrays[f"in{i}_frames"], arrays[f"in{i}_voicing"] = np.array(it[3]), np.array(it[6]), it[7].numpy()
+    arrays.update(w0)
+    arrays.update(w1)
+    save("test_loops", **arrays)
+    return dict(train_loss=float(train_info["loss"]), valid_loss=float(valid_info["loss"]),
+                valid_p2cp_mean=float(valid_info["p2cp_mean"]), test_loss=float(test_info["loss"]),
+                tongue=dict(test_info["tongue"]))
+
+
+def load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_metrics, root_metrics, helpers):
+    """encoder_decoder/evaluation.py and train_phoneme_to_articulation.py, imported as they are.  Name-only shims for the
+    absent mlflow / ujson (module-level imports, never called here); settings.BASE_DIR is pointed at a scratch directory
+    because the training script creates BASE_DIR/tmp/<random> at import time (the reference tree is read-only)."""
+    import tempfile
+    _shim("vt_tools.bs_regularization", regularize_Bsplines=None)
+    ref_init = _load("ref_p2a_init_for_loops", "phoneme_to_articulation/__init__.py")
+    pkg.save_outputs, pkg.tract_variables = ref_init.save_outputs, ref_init.tract_variables
+    pkg.REQUIRED_ARTICULATORS_FOR_TVS = ref_init.REQUIRED_ARTICULATORS_FOR_TVS
+    sys.modules["metrics"] = root_metrics            # evaluation.py:8 `from metrics import ...`
+    ref_eval = _load("phoneme_to_articulation.encoder_decoder.evaluation", "phoneme_to_articulation/encoder_decoder/evaluation.py")
+    _shim("mlflow")
+    _shim("ujson")
+    scratch = tempfile.mkdtemp()
+    os.makedirs(os.path.join(scratch, "tmp"), exist_ok=True)
+    settings.BASE_DIR = scratch
+    sys.modules["phoneme_to_articulation.encoder_decoder.dataset"] = dataset
+    sys.modules["phoneme_to_articulation.encoder_decoder.models"] = models
+    dataset.ArtSpeechDataset = getattr(dataset, "ArtSpeechDataset", None)
+    ref_train = _load("ref_train_script", "train_phoneme_to_articulation.py")
+    return ref_eval, ref_train
+
+
 def main():
+    only = set(sys.argv[1:])  # e.g. `make_golden.py test_loops`: regenerate just that fixture
     install_shims()
     sys.path.insert(0, REF)  # for `settings`, `helpers`
     settings = _load("settings", "settings.py")
@@ -456,6 +570,17 @@ def main():
     _shim("phoneme_to_articulation.tail_clipper", TailClipper=None)
     dataset = _load("ref_ed_dataset", "phoneme_to_articulation/encoder_decoder/dataset.py")
 
+    if only == {"test_loops"}:
+        ref_eval, ref_train = load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_metrics, root_metrics, helpers)
+        res = gen_test_loops(models, dataset, p2a_metrics, ed_metrics, settings, ref_eval, ref_train)
+        path = os.path.join(OUT, "checksums.json")
+        with open(path) as f:
+            allc = json.load(f)
+        allc["cases"]["test_loops"] = res
+        with open(path, "w") as f:
+            json.dump(allc, f, indent=1)
+        print(json.dumps(res, indent=1))
+        return
     checks = {}
     # C1 (SURVEY 8c recipe): ArtSpeech(45, 2), B=4 T=50 lengths [50,40,30,20]
     checks["artspeech_c1"] = gen_artspeech(
@@ -500,6 +625,8 @@ def main():
     _load("phoneme_to_articulation.principal_components.transforms", "phoneme_to_articulation/principal_components/transforms.py")
     pc_losses = _load("phoneme_to_articulation.principal_components.losses", "phoneme_to_articulation/principal_components/losses.py")
     checks.update(gen_pc_autoencoder(ae, pc_losses))
+    ref_eval, ref_train = load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_metrics, root_metrics, helpers)
+    checks["test_loops"] = gen_test_loops(models, dataset, p2a_metrics, ed_metrics, settings, ref_eval, ref_train)
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)
     print(json.dumps(checks, indent=1))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_wg
+from conftest import assert_grad_close, load_golden, split_wg
 from oracle import artspeech_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -291,11 +291,11 @@ def test_single_head_vs_reference_fixture(dev, name):
     _lib.check(L.as_head_bwd(C.byref(dims), C.byref(lay), _lib.ptr(flat), _lib.ptr(out), _lib.ptr(dsig_d), rows, _lib.ptr(dx),
                              _lib.ptr(G), _lib.ptr(ws), _lib.stream_ptr()))
     torch.cuda.synchronize()
-    assert relmax(dx.cpu().numpy(), g["dx"].reshape(rows, inf)) < 2e-4
+    assert_grad_close(dx.cpu().numpy(), g["dx"].reshape(rows, inf), f"{name}: head dx")
     Gc = G.cpu()
     for k, (off, shape) in views.items():
         got = Gc[off:off + _numel(shape)].view(shape).numpy()
-        assert relmax(got, grads[k]) < 2e-4, (k, relmax(got, grads[k]))
+        assert_grad_close(got, grads[k], f"{name}: {k}")
 
 
 # ------------------------------------------------------------------------------------------- models
@@ -329,7 +329,7 @@ def test_artspeech_matches_reference_fixture(dev, name):
     gv = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
     assert set(gv) == set(grads)
     for k in grads:
-        assert relmax(gv[k], grads[k]) < 3e-4, (k, relmax(gv[k], grads[k]))
+        assert_grad_close(gv[k], grads[k], f"{name}: {k}")
     # fused loss gives the same value and the same gradients
     model.zero_grad()
     out2 = model(x, lengths)
@@ -372,7 +372,7 @@ def test_simple_artspeech_matches_reference_fixture(dev):
     assert_close(out.detach().cpu().numpy(), g["out"], what="contours")
     (out * T_(g["dout"], dev)).sum().backward()
     for k, v in model.named_grad_views().items():
-        assert relmax(v.cpu().numpy(), grads[k]) < 3e-4, (k, relmax(v.cpu().numpy(), grads[k]))
+        assert_grad_close(v.cpu().numpy(), grads[k], f"simple_small: {k}")
 
 
 def test_artspeech_vs_oracle_ragged_full_width(dev):
@@ -400,7 +400,7 @@ def test_artspeech_vs_oracle_ragged_full_width(dev):
     assert abs(loss.item() - o_loss) < 1e-6
     og = O.artspeech_bwd(o_dout, cache, 11)
     for k, v in model.named_grad_views().items():
-        assert relmax(v.cpu().numpy(), og[k]) < 3e-4, (k, relmax(v.cpu().numpy(), og[k]))
+        assert_grad_close(v.cpu().numpy(), og[k], f"ragged full width vs oracle: {k}")
 
 
 # ------------------------------------------------------------------------------------------- metrics
@@ -432,6 +432,16 @@ def test_metrics_match_reference_fixture(dev):
     assert_close(root.euclidean_distance(out.detach(), tgt).cpu().numpy(), g["root_euclid"], rtol=1e-6, atol=1e-7, what="root euclid")
     xc, yc = root.pearsons_correlation(out.detach(), tgt)
     assert np.abs(xc.cpu().numpy() - g["x_corr"]).max() < 1e-5 and np.abs(yc.cpu().numpy() - g["y_corr"]).max() < 1e-5
+    # per-utterance slices as run_test passes them (evaluation.py:88-97: outputs[b:b+1, :length]): strided views, no copy,
+    # against the fp64 oracle; a one-frame utterance has zero variance and must give 0 / (0 + eps) = 0, not NaN
+    for b, l in enumerate([int(v) for v in g["lengths"]] + [1]):
+        b = min(b, len(g["lengths"]) - 1)
+        xs, ys = root.pearsons_correlation(out.detach()[b:b + 1, :l], tgt[b:b + 1, :l])
+        ox, oy = O.pearsons_correlation(g["out"][b:b + 1, :l].astype(np.float64), g["tgt"][b:b + 1, :l].astype(np.float64))
+        assert xs.shape == (1, out.shape[2], out.shape[4])
+        assert np.abs(xs.cpu().numpy() - ox).max() < 1e-5 and np.abs(ys.cpu().numpy() - oy).max() < 1e-5, (b, l)
+    with pytest.raises(RuntimeError):
+        root.pearsons_correlation(out.detach().cpu(), tgt.cpu())   # no CPU path
 
 
 def test_tract_variables_match_reference_fixture(dev):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_wg
+from conftest import assert_grad_close, load_golden, split_wg
 from oracle import principal_components_oracle as PO
 
 pytestmark = pytest.mark.gpu
@@ -38,9 +38,7 @@ def test_matches_reference_fixture_forward_and_gradients(name, dev):
     assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 1e-5
     (out * torch.from_numpy(g["dout"]).to(dev)).sum().backward()
     for k, p in m.named_parameters():
-        ref = grads[k]
-        err = np.abs(p.grad.cpu().numpy() - ref).max()
-        assert err < 3e-4 * max(1e-3, np.abs(ref).max()), (k, err, np.abs(ref).max())
+        assert_grad_close(p.grad.cpu().numpy(), grads[k], f"{name}: {k}")
     with torch.no_grad():  # inference path (no saved gates) gives the same numbers
         assert torch.equal(m(tokens, g["lengths"].tolist()), out.detach())
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import ROOT, assert_grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,109 @@ def test_run_epoch_and_run_test(dev, tmp_path):
     assert len(csvs) == 24                               # one per sentence (upper incisor injected)
 
 
+class _CapturedLoader:
+    """Fixed list of collated batches + `.dataset.dataset_config`, as the fixture generator fed the reference's loops."""
+
+    def __init__(self, batches, dataset_config):
+        import types
+        self.batches = batches
+        self.dataset = types.SimpleNamespace(dataset_config=dataset_config)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def test_run_epoch_and_run_test_match_reference_fixture(dev, tmp_path):
+    """tests/golden/test_loops.npz holds what the REFERENCE's run_epoch (train_phoneme_to_articulation.py:45-121) and run_test
+    (encoder_decoder/evaluation.py:17-161) produced on a captured 6-utterance loader: the TRAIN info + the parameters two SGD
+    steps leave, the VALID info with p2cp_mean, the test info dict, one tract_variables.csv, phonemes.csv and contour dumps.
+    The drop-in loops must reproduce all of it from the same state_dict and items."""
+    import csv
+    import train_phoneme_to_articulation as tr
+    from conftest import load_golden
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_collate_fn
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.evaluation import run_test
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDistance
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance
+    from artspeech_amd.settings import DATASET_CONFIG, TRAIN, VALID
+    g = load_golden("test_loops")
+    V, A, E, H, N = (int(v) for v in g["cfg"])
+    arts = [str(a) for a in g["articulators"]]
+    items = []
+    for i in range(len(g["lens"])):
+        items.append((str(g[f"in{i}_id"]), torch.from_numpy(g[f"in{i}_tokens"]), torch.from_numpy(g[f"in{i}_targets"]),
+                      [str(p) for p in g[f"in{i}_phonemes"]], torch.from_numpy(g[f"in{i}_refs"]), torch.tensor([], dtype=torch.int),
+                      [str(f) for f in g[f"in{i}_frames"]], torch.from_numpy(g[f"in{i}_voicing"])))
+    cfg = DATASET_CONFIG["artspeech2"]
+    loader = _CapturedLoader([pad_sequence_collate_fn(items[:3]), pad_sequence_collate_fn(items[3:])], cfg)
+    model = ArtSpeech(V, A, embed_dim=E, hidden_size=H, n_samples=N)
+    w0 = {k[3:]: v for k, v in g.items() if k.startswith("w0.")}
+    w1 = {k[3:]: v for k, v in g.items() if k.startswith("w1.")}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()}, strict=True)
+    model = model.to(dev)
+    crit = EuclideanDistance("none")
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    info = tr.run_epoch(TRAIN, 1, model, loader, opt, crit, device=dev)
+    assert set(info) == {"loss"}
+    assert abs(info["loss"] - float(g["train_loss"])) < 2e-6, (info["loss"], float(g["train_loss"]))
+    for k, v in model.state_dict().items():   # what two optimizer steps changed, element by element
+        # both sides are fp32 parameters: each difference carries up to an ulp of |w| of rounding besides the update itself
+        assert_grad_close(v.cpu().numpy().astype(np.float64) - w0[k], w1[k].astype(np.float64) - w0[k], f"test_loops: SGD delta of {k}",
+                          rtol=1e-3, atol_frac=1e-4, atol_abs=2.5e-7 * max(1.0, float(np.abs(w1[k]).max())))
+    vinfo = tr.run_epoch(VALID, 1, model, loader, opt, crit, fn_metrics={"p2cp_mean": P2CPDistance(cfg)}, device=dev)
+    assert set(vinfo) == {"loss", "p2cp_mean"}
+    assert abs(vinfo["loss"] - float(g["valid_loss"])) < 2e-6
+    # the reference's torch.cdist takes the fp32 matmul expansion for 50-point contours: ~1e-3 off the direct formula
+    assert abs(vinfo["p2cp_mean"] - float(g["valid_p2cp_mean"])) / float(g["valid_p2cp_mean"]) < 2e-3
+    res = run_test(7, model, loader, crit, str(tmp_path), arts, device=dev, regularize_out=False)
+    assert list(res) == ["loss"] + arts
+    assert abs(res["loss"] - float(g["test_loss"])) < 2e-6
+    names = [str(n) for n in g["test_metric_names"]]
+    tol = {"x_corr": ("abs", 2e-5), "y_corr": ("abs", 2e-5), "p2cp": ("rel", 2e-3), "p2cp_mm": ("rel", 2e-3), "med": ("rel", 1e-5),
+           "med_mm": ("rel", 1e-5)}
+    for i, a in enumerate(arts):
+        assert list(res[a]) == names
+        for j, n in enumerate(names):
+            want, got = float(g["test_metrics"][i, j]), res[a][n]
+            err = abs(got - want) / (abs(want) if tol[n][0] == "rel" else 1.0)
+            assert err < tol[n][1], (a, n, got, want)
+    # files of one sentence: same names, same table layout
+    sdir = os.path.join(str(tmp_path), "7", "sent4")
+    assert len(os.listdir(os.path.join(str(tmp_path), "7"))) == int(g["n_sentence_dirs"])
+    assert sorted(os.listdir(os.path.join(sdir, "contours"))) == [str(f) for f in g["contour_files"]]
+    with open(os.path.join(sdir, "phonemes.csv")) as f:
+        assert [list(r) for r in csv.reader(f)] == [[str(c) for c in r] for r in g["phonemes_csv"]]
+    with open(os.path.join(sdir, "tract_variables.csv")) as f:
+        rows = list(csv.reader(f))
+    cols = rows[0]
+    assert cols == [str(c) for c in g["tv_columns"]]
+    assert [r[cols.index("frame")] for r in rows[1:]] == [str(v) for v in g["tv_frames"]]
+    assert [r[cols.index("phoneme")] for r in rows[1:]] == [str(v) for v in g["tv_phonemes"]]
+    num = [str(c) for c in g["tv_numeric_columns"]]
+    got = np.array([[float(r[cols.index(c)]) for c in num] for r in rows[1:]])
+    want = g["tv_values"]
+    # targets are inputs: the same closest pairs, their coordinates bit for bit
+    tcols = [j for j, c in enumerate(num) if "_target_poc_" in c]
+    assert np.array_equal(got[:, tcols], want[:, tcols])
+    # the distance itself: the reference takes it from torch.cdist, which for 50-point sets evaluates |u|^2 + |v|^2 - 2 u.v in
+    # fp32 (error ~ 2e-7 / d in d); the HIP kernel takes the direct difference (error ~ 1e-7 * d)
+    dcols = [j for j, c in enumerate(num) if c.endswith("_target")]
+    assert (np.abs(got[:, dcols] - want[:, dcols]) <= 2e-7 / np.maximum(want[:, dcols], 1e-4) + 1e-7).all()
+    vcols = [j for j, c in enumerate(num) if c.endswith("_pred")]
+    assert (np.abs(got[:, vcols] - want[:, vcols]) <= 2e-7 / np.maximum(want[:, vcols], 1e-4) + 1e-5).all()
+    # predicted closest points: the same points except where two candidate pairs tie within the 1e-6 the contours differ by
+    pcols = [j for j, c in enumerate(num) if "_pred_poc_" in c]
+    same = np.abs(got[:, pcols] - want[:, pcols]) < 1e-5
+    assert same.mean() > 0.97, same.mean()
+    frame0 = str(g["in4_frames"][0])
+    assert np.abs(np.load(os.path.join(sdir, "contours", f"{frame0}_tongue.npy")) - g["pred_tongue_frame0"]).max() < 1e-5
+    assert np.array_equal(np.load(os.path.join(sdir, "contours", f"{frame0}_upper-incisor_true.npy")), g["true_incisor_frame0"])
+
+
 def test_train_step_engine_equals_module_path(dev):
     from artspeech_amd.engine import TrainStep
     from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
@@ -84,6 +187,41 @@ def test_train_step_engine_equals_module_path(dev):
     assert abs(step.loss.item() - ref_loss) < 1e-7
     assert torch.equal(step.grads, ref_grad)              # same kernels, same order: bit-identical
     assert torch.allclose(model.flat.data, after_torch, rtol=1e-5, atol=1e-7)  # fused Adam == torch.optim.Adam
+
+
+def test_two_models_interleaved_on_two_streams(dev):
+    """The library's side stream, fork/join events and heads-done event belong to the (device, caller stream) pair: two
+    models stepped alternately on two streams (no host sync in between) leave exactly the losses and gradients that each
+    leaves when it runs alone."""
+    from artspeech_amd.engine import TrainStep
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    B, T, A = 8, 48, 3
+    lengths = torch.tensor([48, 45, 40, 33, 21, 12, 5, 1], dtype=torch.int32)
+    cases = []
+    for seed in (11, 12):
+        torch.manual_seed(seed)
+        model = ArtSpeech(20, A).to(dev)
+        x = torch.randint(1, 20, (B, T), device=dev)
+        tgt = torch.rand(B, T, A, 2, 50, device=dev)
+        cases.append((model, x, tgt, TrainStep(model, B, T, optimizer=False)))
+    scale = 1.0 / (int(lengths.sum()) * A * 50)
+    ldev = lengths.to(dev)
+    alone = []
+    for model, x, tgt, step in cases:            # reference: each alone on the default stream
+        step.forward_backward(x, ldev, tgt, scale)
+        torch.cuda.synchronize()
+        alone.append((step.loss.clone(), step.grads.clone()))
+        step.grads.zero_()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for _ in range(3):                            # interleaved, no synchronisation between the launches
+        for (model, x, tgt, step), st in zip(cases, streams):
+            with torch.cuda.stream(st):
+                step.forward_backward(x, ldev, tgt, scale)
+    torch.cuda.synchronize()
+    for (model, x, tgt, step), (loss, grads) in zip(cases, alone):
+        assert torch.equal(step.loss, loss)
+        assert torch.equal(step.grads, grads)
 
 
 def test_gru_dropout_training_mode(dev):
@@ -131,13 +269,59 @@ def test_gru_dropout_training_mode(dev):
     o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
     og = O.artspeech_bwd(o_dout, cache, A)
     for k, v in model.named_grad_views().items():
-        err = np.abs(v.cpu().numpy() - og[k]).max() / max(np.abs(og[k]).max(), 1e-30)
-        assert err < 3e-4, (k, err)
+        assert_grad_close(v.cpu().numpy(), og[k], f"gru dropout vs oracle: {k}")
     # eval mode ignores dropout
     model.eval()
     with torch.no_grad():
         out_eval = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
     o_eval, _ = O.artspeech_fwd(sd, x, lengths, A)
+    assert np.abs(out_eval.cpu().numpy() - o_eval).max() < 1e-5
+
+
+def test_simple_artspeech_dropout_training_mode(dev):
+    """SimpleArtSpeech(dropout=p).train(): nn.Dropout on the embedded frames (reference models.py:64,85).  Exact forward /
+    backward parity with the oracle GIVEN the mask the library generated; eval mode ignores p."""
+    from artspeech_amd import _lib
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import SimpleArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    from oracle import artspeech_oracle as O
+    L = _lib.lib()
+    p, B, T, A, E = 0.25, 3, 21, 2, 64
+    torch.manual_seed(3)
+    model = SimpleArtSpeech(20, A, dropout=p).to(dev)
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    rng = np.random.RandomState(1)
+    x = rng.randint(0, 20, (B, T))
+    tgt = rng.rand(B, T, A, 2, 50).astype(np.float32)
+    lengths = np.array([T, T, T])
+    model.train()
+    torch.manual_seed(99)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # what forward() will draw
+    torch.manual_seed(99)
+    out = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
+    loss = masked_euclidean_loss(out, torch.from_numpy(tgt).to(dev), lengths)
+    loss.backward()
+    scale = torch.empty(B * T * E, device=dev)
+    _lib.check(L.as_dropout_fwd(_lib.ptr(torch.ones_like(scale)), _lib.ptr(scale), scale.numel(), p, seed, _lib.stream_ptr()))
+    scale = scale.view(B, T, E).cpu().numpy()
+    assert 0.6 < (scale > 0).mean() < 0.9
+    o_out, cache = O.simple_artspeech_fwd(sd, x, A, embed_scale=scale)
+    err = np.abs(out.detach().cpu().numpy() - o_out).max()
+    assert err < 1e-5, err
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    og = O.simple_artspeech_bwd(o_dout, cache, A)
+    for k, v in model.named_grad_views().items():
+        a, b = v.cpu().numpy().astype(np.float64), og[k]
+        viol = np.abs(a - b) - (1e-4 * np.abs(b) + 1e-6 * np.abs(b).max() + 1e-9)
+        assert viol.max() <= 0, (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    # another draw, another mask; eval mode is deterministic and ignores p
+    out2 = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
+    assert not torch.equal(out2, out)
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
+    o_eval, _ = O.simple_artspeech_fwd(sd, x, A)
     assert np.abs(out_eval.cpu().numpy() - o_eval).max() < 1e-5
 
 

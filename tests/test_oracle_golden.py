@@ -215,3 +215,57 @@ def test_semipolar_grid_intersection_oracle_properties():
     ext = np.array([[0.9, 0.0], [0.9, 1.0]])
     flags, pi, pe = O.intersect_semipolar_grid(zig, ext, line)
     assert flags.tolist() == [3] and np.allclose(pi[0], [0.65, 0.5]) and np.allclose(pe[0], [0.9, 0.5])
+
+
+def test_oracle_reproduces_the_reference_training_and_test_loops():
+    """tests/golden/test_loops.npz: what the reference's run_epoch / run_test produced on a captured 6-utterance loader
+    (make_golden.py::gen_test_loops).  The oracle, stepped by hand the way run_epoch steps the model (forward, masked mean,
+    backward, SGD update, twice), must land on the same losses and the same parameters; its metric functions on the trained
+    parameters must give the test loop's info dict."""
+    g = load_golden("test_loops")
+    V, A, E, H, N = (int(v) for v in g["cfg"])
+    n_utt = len(g["lens"])
+    w = {k[3:]: v.astype(np.float64) for k, v in g.items() if k.startswith("w0.")}
+    w1 = {k[3:]: v for k, v in g.items() if k.startswith("w1.")}
+
+    def collate(idx):  # pad_sequence_collate_fn: sort by length, descending (stable), zero padding
+        order = sorted(idx, key=lambda i: -len(g[f"in{i}_tokens"]))
+        lens = np.array([len(g[f"in{i}_tokens"]) for i in order])
+        T = lens.max()
+        x = np.zeros((len(order), T), np.int64)
+        tgt = np.zeros((len(order), T, A, 2, N), np.float32)
+        for r, i in enumerate(order):
+            x[r, :lens[r]], tgt[r, :lens[r]] = g[f"in{i}_tokens"], g[f"in{i}_targets"]
+        return x, tgt, lens
+
+    batches = [collate(range(0, 3)), collate(range(3, n_utt))]
+    losses = []
+    for x, tgt, lens in batches:
+        out, cache = O.artspeech_fwd(w, x, lens, A)
+        loss, dout = O.masked_euclid_loss(out, tgt, lens)
+        grads = O.artspeech_bwd(dout, cache, A)
+        losses.append(loss)
+        w = {k: w[k] - 0.05 * grads[k] for k in w}
+    assert abs(np.mean(losses) - float(g["train_loss"])) < 1e-6
+    for k in w1:
+        d_ref, d_or = w1[k].astype(np.float64) - g["w0." + k], w[k] - g["w0." + k]
+        # the fixture's parameters are fp32: w1 - w0 carries up to an ulp of |w| of rounding on top of the update itself
+        assert np.abs(d_or - d_ref).max() <= 1e-3 * np.abs(d_ref).max() + 2.5e-7 * max(1.0, np.abs(w1[k]).max()), k
+    # evaluation on the trained parameters (the fixture's own, so that this half does not inherit the first half's error)
+    w1d = {k: v.astype(np.float64) for k, v in w1.items()}
+    vloss, per_art = [], {n: [[] for _ in range(A)] for n in ("x_corr", "y_corr", "med")}
+    for x, tgt, lens in batches:
+        out, _ = O.artspeech_fwd(w1d, x, lens, A)
+        vloss.append(O.masked_euclid_loss(out, tgt, lens)[0])
+        for b, l in enumerate(lens):
+            xc, yc = O.pearsons_correlation(out[b:b + 1, :l], tgt[b:b + 1, :l].astype(np.float64))
+            med = O.euclidean_distance_metric(out[b:b + 1, :l], tgt[b:b + 1, :l].astype(np.float64)).mean(1)[0]
+            for a in range(A):
+                per_art["x_corr"][a].append(xc.mean(-1)[0, a])
+                per_art["y_corr"][a].append(yc.mean(-1)[0, a])
+                per_art["med"][a].append(med[a])
+    assert abs(np.mean(vloss) - float(g["valid_loss"])) < 1e-6 and abs(np.mean(vloss) - float(g["test_loss"])) < 1e-6
+    names = [str(n) for n in g["test_metric_names"]]
+    for a in range(A):
+        for n in ("x_corr", "y_corr", "med"):
+            assert abs(np.mean(per_art[n][a]) - g["test_metrics"][a, names.index(n)]) < 2e-6, (a, n)
