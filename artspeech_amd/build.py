@@ -19,6 +19,7 @@ SOURCES = {
     "prof.hip": [],
     "gemm_f32.hip": [],
     "wgrad_f32.hip": [],
+    "lin_f32.hip": [],
     "rowops.hip": [],
     "gru.hip": [],
     "lstm.hip": [],

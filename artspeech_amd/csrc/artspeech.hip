@@ -18,6 +18,7 @@
 #include <mutex>
 #include <vector>
 
+#include "gemm_internal.h"
 #include "rowops.h"
 
 namespace {
@@ -49,7 +50,7 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.b1f = c.take(A * D);
     w.w2f = c.take(A * D * D);
     w.b2f = c.take(A * D);
-    w.w3f = c.take(A * O * D);
+    w.w3f = c.take(A * as_round_up(O, 32) * D);  // rows O .. Opad-1 of every head are zeros (head_fold)
     w.b3f = c.take(A * O);
     w.r1 = c.take(rows * A * D);
     w.r1hat = c.take(rows * A * D);
@@ -157,7 +158,7 @@ int head_fold(const as_dims& d, const as_layout& L, const float* P, int64_t rows
     const HeadWs w = head_ws(d, rows);
     AS_STEP("head.fold", st, as_fold(P + L.w1, P + L.ln1_g, P + L.ln1_b, P + L.b1, ws + w.w1f, ws + w.b1f, A, D, H, st));
     AS_STEP("head.fold", st, as_fold(P + L.w2, P + L.ln2_g, P + L.ln2_b, P + L.b2, ws + w.w2f, ws + w.b2f, A, D, D, st));
-    AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st));
+    AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st, (int)as_round_up(O, 32)));
     return 0;
 }
 
@@ -168,18 +169,60 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     AS_STEP("head.norm0", st, as_normalize_fwd(x, ws + w.xhat, ws + w.rstd0, rows, H, st));
-    // GEMM 1: all heads at once (shared x_hat): r1 [rows][A*D]
-    AS_STEP("head.gemm1", st, gemm_nt(ws + w.xhat, H, ws + w.w1f, H, ws + w.r1, (long)A * D, ws + w.b1f, R, A * D, H, 1, st));
-    AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st,
-                                               reinterpret_cast<unsigned long long*>(ws + w.bits1)));
-    // GEMM 2: batched over heads on [rows][A][D]
-    AS_STEP("head.gemm2", st, gemm_nt(ws + w.r1hat, (long)A * D, ws + w.w2f, D, ws + w.r2, (long)A * D, ws + w.b2f, R, D, D, 1, st, A, D,
-                   (long)D * D, D, D));
-    AS_STEP("head.norm2", st, as_normalize_fwd(ws + w.r2, ws + w.r2hat, ws + w.rstd2, rows * A, D, st,
-                                               reinterpret_cast<unsigned long long*>(ws + w.bits2)));
-    // GEMM 3: sigmoid epilogue writes out[rows][A][2][N]
-    AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, (long)A * D, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D, (long)O * D, O,
-                   O));
+    const long AD = (long)A * D;
+    const int Opad = (int)as_round_up(O, 32);
+    unsigned long long* bits1 = reinterpret_cast<unsigned long long*>(ws + w.bits1);
+    unsigned long long* bits2 = reinterpret_cast<unsigned long long*>(ws + w.bits2);
+    // Linear 1 + ReLU + LayerNorm 2 in one kernel per (96 frames, head): r1hat, rstd1, ReLU bits (lin_f32.hip); else the
+    // general GEMM (all heads at once: shared x_hat, N = A*256 columns) followed by the row kernel
+    as_lin l1{};
+    l1.A = ws + w.xhat; l1.lda = H; l1.a_batch = 0;
+    l1.B = ws + w.w1f; l1.ldb = H; l1.b_batch = (long)D * H; l1.b_kc = 1;
+    l1.C = ws + w.r1hat; l1.ldc = AD; l1.c_batch = D;
+    l1.bias = ws + w.b1f; l1.bias_batch = D;
+    l1.M = R; l1.N = D; l1.K = H; l1.batch = A; l1.epi = 1;
+    l1.rstd = ws + w.rstd1; l1.bits = bits1;
+    int took;
+    {
+        AS_PROF("head.gemm1", st);
+        took = as_lin_try(&l1, st);
+        AS_REQUIRE(took >= 0, took, "head gemm1: launch failed");
+    }
+    if (!took) {
+        AS_STEP("head.gemm1", st, gemm_nt(ws + w.xhat, H, ws + w.w1f, H, ws + w.r1, AD, ws + w.b1f, R, A * D, H, 1, st));
+        AS_STEP("head.norm1", st, as_normalize_fwd(ws + w.r1, ws + w.r1hat, ws + w.rstd1, rows * A, D, st, bits1));
+    }
+    // Linear 2 + ReLU + LayerNorm 3, batched over heads on [rows][A][D]
+    as_lin l2 = l1;
+    l2.A = ws + w.r1hat; l2.lda = AD; l2.a_batch = D;
+    l2.B = ws + w.w2f; l2.ldb = D; l2.b_batch = (long)D * D;
+    l2.C = ws + w.r2hat; l2.bias = ws + w.b2f;
+    l2.K = D; l2.rstd = ws + w.rstd2; l2.bits = bits2;
+    {
+        AS_PROF("head.gemm2", st);
+        took = as_lin_try(&l2, st);
+        AS_REQUIRE(took >= 0, took, "head gemm2: launch failed");
+    }
+    if (!took) {
+        AS_STEP("head.gemm2", st, gemm_nt(ws + w.r1hat, AD, ws + w.w2f, D, ws + w.r2, AD, ws + w.b2f, R, D, D, 1, st, A, D,
+                       (long)D * D, D, D));
+        AS_STEP("head.norm2", st, as_normalize_fwd(ws + w.r2, ws + w.r2hat, ws + w.rstd2, rows * A, D, st, bits2));
+    }
+    // Linear 3 (x_coords | y_coords) with the sigmoid epilogue writes out[rows][A][2][N]
+    as_lin l3{};
+    l3.A = ws + w.r2hat; l3.lda = AD; l3.a_batch = D;
+    l3.B = ws + w.w3f; l3.ldb = D; l3.b_batch = (long)Opad * D; l3.b_kc = 1;
+    l3.C = out; l3.ldc = (long)A * O; l3.c_batch = O;
+    l3.bias = ws + w.b3f; l3.bias_batch = O;
+    l3.M = R; l3.N = O; l3.K = D; l3.batch = A; l3.act = 2; l3.epi = 0;
+    {
+        AS_PROF("head.gemm3", st);
+        took = as_lin_try(&l3, st);
+        AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
+    }
+    if (!took)
+        AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, AD, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D,
+                       (long)Opad * D, O, O));
     return 0;
 }
 
@@ -197,13 +240,41 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     const long AD = (long)A * D, AO = (long)A * O;
     const float* dpre3 = presig ? dout : ws + w.dpre3;
     if (!presig) AS_STEP("headb.sigmoid", st, as_sigmoid_bwd(out, dout, ws + w.dpre3, rows * AO, st));
-    AS_STEP("headb.dx3", st, gemm_nn(dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)O * D, D));
-    // the ReLU masks come as bit words (32 B per row) instead of the activations themselves (1 KB per row)
-    AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, nullptr, ws + w.dz2, rows * A, D, st,
-                                                reinterpret_cast<const unsigned long long*>(ws + w.bits2)));
-    AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
-    AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, nullptr, ws + w.dz1, rows * A, D, st,
-                                                reinterpret_cast<const unsigned long long*>(ws + w.bits1)));
+    const int Opad = (int)as_round_up(O, 32);
+    const unsigned long long* bits1 = reinterpret_cast<const unsigned long long*>(ws + w.bits1);
+    const unsigned long long* bits2 = reinterpret_cast<const unsigned long long*>(ws + w.bits2);
+    // d(r2hat) = dpre3 . W3' through LayerNorm 3 and ReLU 2 in one kernel (the reduction runs over Opad: the folded
+    // weights' rows O .. Opad-1 are zeros); else GEMM + the row kernel.  The ReLU masks come as bit words (32 B per row).
+    as_lin b3{};
+    b3.A = dpre3; b3.lda = AO; b3.a_batch = O;
+    b3.B = ws + w.w3f; b3.ldb = D; b3.b_batch = (long)Opad * D; b3.b_kc = 0;
+    b3.C = ws + w.dz2; b3.ldc = AD; b3.c_batch = D;
+    b3.M = R; b3.N = D; b3.K = Opad; b3.ka_valid = O; b3.batch = A; b3.epi = 2;
+    b3.xhat = ws + w.r2hat; b3.ldx = AD; b3.x_batch = D; b3.rstd_in = ws + w.rstd2; b3.bits_in = bits2;
+    int took;
+    {
+        AS_PROF("headb.dx3", st);
+        took = as_lin_try(&b3, st);
+        AS_REQUIRE(took >= 0, took, "head dx3: launch failed");
+    }
+    if (!took) {
+        AS_STEP("headb.dx3", st, gemm_nn(dpre3, AO, ws + w.w3f, D, ws + w.dz2, AD, R, D, O, st, A, O, (long)Opad * D, D));
+        AS_STEP("headb.norm2", st, as_normalize_bwd(ws + w.dz2, ws + w.r2hat, ws + w.rstd2, nullptr, ws + w.dz2, rows * A, D, st, bits2));
+    }
+    as_lin b2 = b3;
+    b2.A = ws + w.dz2; b2.lda = AD; b2.a_batch = D;
+    b2.B = ws + w.w2f; b2.b_batch = (long)D * D;
+    b2.C = ws + w.dz1; b2.K = D; b2.ka_valid = D;
+    b2.xhat = ws + w.r1hat; b2.rstd_in = ws + w.rstd1; b2.bits_in = bits1;
+    {
+        AS_PROF("headb.dx2", st);
+        took = as_lin_try(&b2, st);
+        AS_REQUIRE(took >= 0, took, "head dx2: launch failed");
+    }
+    if (!took) {
+        AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
+        AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, nullptr, ws + w.dz1, rows * A, D, st, bits1));
+    }
     // N = H columns only (100 x 2 tiles of 64 x 64) under a 2816-long reduction: split K over the main-stream slab
     AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st, 1, 0, 0, 0, ws + w.slab));
     AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));

@@ -5,3 +5,21 @@
 // wgrad_f32.hip: weight-gradient shapes (both operands reduction-strided, long reduction).  1 = taken and launched,
 // 0 = not a shape for this kernel (the caller continues with the general kernel), < 0 = error.
 int as_wgrad_try(const as_gemm* g, hipStream_t st);
+
+// lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):
+//   C[bz] = epilogue(A[bz] [M][K] . B[bz]),  B[bz] = [N][K] (b_kc: forward) or [K][N] (backward); N <= 256, K % 32 == 0.
+//   epi 0: act(. + bias) (act as as_gemm: 0 none, 1 ReLU, 2 sigmoid)
+//   epi 1: x = relu(. + bias); C = (x - mean) * rstd over the 256 features; rstd [M][batch]; bits [M][batch][4] = x > 0
+//   epi 2: g = .; C = relu'(bits_in) * rstd_in * (g - mean g - xhat * mean(g xhat))   (LayerNorm + ReLU backward)
+// ka_valid (0 = K): k >= ka_valid of A is not read (the caller's B has zero rows there).  Strides in floats.
+// 1 = launched, 0 = not a case for this kernel (take the general GEMM + row kernels), < 0 = error.
+struct as_lin {
+    const float* A; long lda, a_batch;
+    const float* B; long ldb, b_batch; int b_kc;
+    float* C; long ldc, c_batch;
+    const float* bias; long bias_batch;
+    int M, N, K, ka_valid, batch, act, epi;
+    float* rstd; unsigned long long* bits;
+    const float* xhat; long ldx, x_batch; const float* rstd_in; const unsigned long long* bits_in;
+};
+int as_lin_try(const as_lin* a, hipStream_t st);

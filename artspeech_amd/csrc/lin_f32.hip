@@ -1,0 +1,369 @@
+// Linear layers of the ArticulatorPredictor heads (encoder_decoder/models.py:10-33) with their LayerNorms fused into the
+// GEMM that produces (forward) or consumes (backward) the normalised activations:
+//
+//   forward   x_hat_next = LN(relu(x_hat . W'^T + b'))        C = A[M][K] . B[N][K]^T   (B reduction-contiguous, "NT")
+//   backward  dz = relu' * LNbwd(dz_next . W')                 C = A[M][K] . B[K][N]     (B output-contiguous, "NN")
+//
+// (W', b' = the weights with the LayerNorm affine folded in; LN = affine-free normalisation over the 256 features of one
+// head.)  Unfused, every such layer moves its [rows][A][256] activation through HBM three to five times (GEMM store,
+// normalize load + store, and in the backward x_hat besides): 216-288 MB per layer at B*T = 6400 against 72-144 MB here.
+//
+// One workgroup owns BM = 64 frames x the 256 features of ONE head, so a row's LayerNorm statistics never leave the
+// workgroup.  8 waves side by side along the features (32 columns x all 64 rows each: two accumulators).  60 KB of LDS and
+// < 128 VGPRs: TWO workgroups per CU, so that one's prologue (DMA latency), barriers and epilogue (a pure memory phase:
+// 64 KB of x_hat out, in the backward 64 KB in as well) run under the other's MFMAs.  (One 96/128-row workgroup per CU with
+// a deeper ring was measured first: every CU reached its epilogue at the same moment, 35-43 us of a 130 us launch were
+// epilogue with the matrix pipes idle.)
+// Operands stream through a 3-slot LDS ring of 16-deep k-tiles filled by LDS-DMA (global_load_lds_dwordx4, two k-tiles in
+// flight, counted vmcnt + raw barriers) like wgrad_f32.hip.  Reduction-contiguous operands keep their global layout in LDS
+// ([row][16 k], no padding possible under DMA) with the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 on the
+// SOURCE address: a lane then takes four consecutive k of its row with ONE conflict-free ds_read_b128, which feed four
+// MFMA k-steps (k-step j of an 8-group pairs k = j in lanes 0-31 with k = j + 4 in lanes 32-63, for both operands alike).
+// Epilogue, 32 rows at a time: the accumulators go to LDS (the ring's memory), then one wave per row does exactly what
+// normalize_fwd_kernel / normalize_bwd_kernel (rowops.hip) do, reading the GEMM result from LDS instead of HBM.
+#include <cstdlib>
+
+#include "gemm_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BN = 256, BK = 16, NT = 512, NBUF = 3;
+enum { EPI_PLAIN = 0, EPI_LNF = 1, EPI_LNB = 2 };
+
+struct LinK {
+    const float* A; long lda, a_batch;
+    const float* B; long ldb, b_batch;
+    float* C; long ldc, c_batch;
+    const float* bias; long bias_batch;
+    int M, N, K, ka_valid, batch, act, tiles_m;
+    int stagger;
+    unsigned long long* dbg; long dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps), normally null
+    int abl;  // diagnostic (AS_LIN_ABL): 1 = return before the epilogue, 2 = no DMA after the prologue
+    float eps;
+    float* rstd;                      // EPI_LNF out: [M][batch]
+    unsigned long long* bits;         // EPI_LNF out: [M][batch][4]: v > 0 per feature
+    const float* xhat; long ldx, x_batch;   // EPI_LNB in: the normalised activations this layer's LayerNorm produced
+    const float* rstd_in;             // EPI_LNB in: [M][batch]
+    const unsigned long long* bits_in;
+};
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at the wave-uniform byte
+// address `lds_dst` (+ lane * 16).  Inline asm on purpose: with the builtin hipcc knows that the instruction writes LDS and
+// puts an s_waitcnt vmcnt(0) in front of the next ds_read -- every k-tile then waits for the DMAs it has just issued (seen
+// in this kernel's ISA; the ring's counted waits + barriers below are what orders a slot's reads behind its DMAs).
+// M0 is compiler-reserved: saved and restored inside the one statement that uses it.
+__device__ __forceinline__ void glds16(const float* src, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // derived from the wave index: uniform, but only the hardware knows
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {  // byte address inside the workgroup's LDS, wave-uniform
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p);
+}
+
+// Sum over the 64 lanes, result in every lane.  Four DPP steps give every lane its 16-lane row total (xor 1, xor 2, mirror of
+// 8, mirror of 16: ~8 cycles each); the four row totals are read out with v_readlane and added as wave-uniform values.
+// (as_wave_sum's six __shfl_xor steps are six dependent LDS-crossbar round trips: 12 of them per LayerNorm row made the
+// epilogue longer than the GEMM's main loop.)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+__device__ __forceinline__ void lds_barrier() {  // LDS hazards only: unlike __syncthreads() it leaves global stores in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int BM, bool B_KC, int EPI>
+__global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
+    constexpr int TM = BM / 32;
+    constexpr int TILE = BK * (BM + BN);
+    constexpr int PA_TOTAL = BM / 16;    // 1-KiB DMA pieces of the A tile (16 rows x 16 k each)
+    constexpr int RING = NBUF * TILE, EPIT = 32 * BN;
+    __shared__ __attribute__((aligned(16))) float smem[RING > EPIT ? RING : EPIT];
+
+    const int tm = blockIdx.x % g.tiles_m, bz = blockIdx.x / g.tiles_m;
+    const int m0 = tm * BM;
+    const float* __restrict__ A = g.A + (long)bz * g.a_batch;
+    const float* __restrict__ B = g.B + (long)bz * g.b_batch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- DMA sources (per lane) and destinations (per wave)
+    // A: piece p = rows 16p .. 16p+15 of the tile; lane -> row 16p + (lane >> 2), LDS chunk slot lane & 3, which receives the
+    // global chunk slot ^ ((row >> 2) & 3).  Every wave issues ONE A piece: waves 4-7 re-issue pieces 0-3 (identical bytes to
+    // identical addresses) so that all waves count the same number of DMAs per k-tile.
+    // Chunks at or beyond ka_valid (a reduction padded up to a multiple of 16 whose B rows there are zero) re-read chunk 0.
+    const int pa = wave % PA_TOTAL;
+    const int ra = pa * 16 + (lane >> 2);
+    const int a_gc = ((lane & 3) ^ ((ra >> 2) & 3)) * 4;
+    const float* a_src = A + (long)min(m0 + ra, g.M - 1) * g.lda + a_gc;
+    // B: 16 pieces, two per wave.  B_KC: piece = 16 rows (output features) x 16 k, swizzled like A.  Else: piece = one k row
+    // of 256 output features.
+    const float* b_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave * 2 + j;
+        if (B_KC) {
+            const int r = p * 16 + (lane >> 2);
+            const int gc = (lane & 3) ^ ((r >> 2) & 3);
+            b_src[j] = B + (long)min(r, g.N - 1) * g.ldb + gc * 4;
+        } else {
+            b_src[j] = B + (long)p * g.ldb + min(lane * 4, g.N - 4);
+        }
+    }
+    const unsigned smem_base = lds_addr(smem);
+    auto issue = [&](int kt) {
+        const unsigned base = smem_base + (unsigned)((kt % NBUF) * TILE) * 4u;
+        const int k0 = kt * BK;
+        const bool ok = k0 + a_gc + 4 <= g.ka_valid;
+        glds16(a_src + (ok ? k0 : -a_gc), base + (unsigned)(pa * 1024));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            glds16(b_src[j] + (B_KC ? (long)k0 : (long)k0 * g.ldb), base + (unsigned)((BK * BM + (wave * 2 + j) * 256) * 4));
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int nk = g.K / BK;
+    const bool stamp = g.dbg != nullptr && tid == 0 && blockIdx.x < g.dbg_max;
+    if (stamp) {
+        unsigned long long* d = g.dbg + 8L * blockIdx.x;
+        d[0] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_memrealtime();
+        d[6] = 0;
+        d[5] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20) << 32);
+    }
+    // Two workgroups share a CU and would run in lockstep (same start, same tile time): both in their prologue, both in
+    // their main loop, both in their epilogue -- nothing overlaps.  The second wave of the first fill (blocks 256..511 under
+    // round-robin dispatch: speed only) starts half a tile late; every later workgroup inherits the phase of the slot it takes.
+    if (g.stagger && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < nk * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
+    }
+    const int swz = (l31 >> 2) & 3;   // rows i * 32 + l31 and wave * 32 + l31 share it (32 = 0 mod 16)
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (stamp) g.dbg[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) issue(kt + 2);
+        const float* tile = smem + (kt % NBUF) * TILE;
+        const float* a_s = tile + l31 * BK;
+        const float* b_s = tile + BK * BM;
+#pragma unroll
+        for (int cc = 0; cc < BK / 8; ++cc) {
+            const int slot = ((2 * cc + lh) ^ swz) * 4;
+            float4 av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + slot);
+            float bv[4];
+            if (B_KC) {
+                const float4 t = *reinterpret_cast<const float4*>(b_s + (wave * 32 + l31) * BK + slot);
+                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float a = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[i], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (stamp) g.dbg[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    if (g.abl == 1) {
+        if (acc[0][0] == 123.456f) g.C[0] = acc[0][0];  // keep the loop alive
+        return;
+    }
+
+    // ---- epilogue.  D[row][col]: col = wave * 32 + l31, row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh
+    const int col = wave * 32 + l31;
+    if (EPI == EPI_PLAIN) {
+        if (col < g.N) {
+            const float bj = g.bias ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+            float* c0 = g.C + (long)bz * g.c_batch + col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M) {
+                        float v = acc[i][r] + bj;
+                        if (g.act == 1) v = fmaxf(v, 0.f);
+                        else if (g.act == 2) v = as_sigmoid(v);
+                        c0[(long)row * g.ldc] = v;
+                    }
+                }
+        }
+        return;
+    }
+    const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    constexpr float inv_d = 1.0f / BN;
+    // backward: everything this wave reads from global memory (x_hat rows, rstd, mask words of its 4 rows per 32-row
+    // block) is requested up front -- vector memory operations retire in order, so a load issued behind the first block's
+    // stores would wait for them
+    // (rstd and the mask words are wave-uniform: scalar loads, which do not queue behind the vector stores)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float h[TM][4][4];
+    if (EPI == EPI_LNB) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long row = min((long)m0 + i * 32 + wave_u + 8 * q, (long)g.M - 1);
+                const float* xr = g.xhat + (long)bz * g.x_batch + row * g.ldx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[i][q][c] = xr[lane + 64 * c];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {   // 32 rows at a time through 32 KB of LDS
+        if (i > 0) lds_barrier();    // the previous block's rows are all read
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[i][r] + bj;
+            if (EPI == EPI_LNF) v = fmaxf(v, 0.f);
+            smem[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // one wave per row; lane holds features lane + 64 c
+            const int rr = wave_u + 8 * q;
+            const long row = m0 + i * 32 + rr;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = smem[rr * BN + lane + 64 * c];
+            float* o = g.C + (long)bz * g.c_batch + row * g.ldc;
+            if (EPI == EPI_LNF) {
+                unsigned long long pos[4];
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s += v[c];
+                    pos[c] = __ballot(v[c] > 0.f);
+                }
+                const float mean = wave_sum(s) * inv_d;
+                float qq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] -= mean;
+                    qq += v[c] * v[c];
+                }
+                const float rs = 1.0f / sqrtf(wave_sum(qq) * inv_d + g.eps);
+                if (row < g.M) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[lane + 64 * c] = v[c] * rs;
+                    if (lane == 0) g.rstd[row * g.batch + bz] = rs;
+                    if (lane < 4) g.bits[(row * g.batch + bz) * 4 + lane] = lane == 0 ? pos[0] : lane == 1 ? pos[1] : lane == 2 ? pos[2] : pos[3];
+                }
+            } else {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s1 += v[c];
+                    s2 += v[c] * h[i][q][c];
+                }
+                const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+                if (row < g.M) {
+                    const float rs = g.rstd_in[row * g.batch + bz];
+                    const unsigned long long* mw = g.bits_in + (row * g.batch + bz) * 4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float d = rs * (v[c] - m1 - h[i][q][c] * m2);
+                        o[lane + 64 * c] = (mw[c] >> lane) & 1ull ? d : 0.f;
+                    }
+                }
+            }
+        }
+    }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g.dbg[8L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+        g.dbg[8L * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool B_KC, int EPI>
+int launch(const LinK& k, hipStream_t st) {
+    LinK kk = k;
+    kk.tiles_m = as_cdiv(k.M, 64);
+    hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI>), dim3((unsigned)((long)kk.tiles_m * k.batch)), dim3(NT), 0, st, kk);
+    AS_LAUNCH_CHECK("as_lin_f32");
+    return 0;
+}
+
+unsigned long long* g_dbg = nullptr;
+long g_dbg_max = 0;
+
+}  // namespace
+
+extern "C" void as_lin_debug_stamps(uint64_t* buf, int64_t max_workgroups) {
+    g_dbg = (unsigned long long*)buf;
+    g_dbg_max = buf ? max_workgroups : 0;
+}
+
+// see gemm_internal.h.  Returns 1 if launched, 0 if the arguments are outside what the kernel is built for (the caller
+// then takes the general GEMM + row kernels), < 0 on a launch error.
+int as_lin_try(const as_lin* a, hipStream_t st) {
+    static const bool off = getenv("AS_NO_LIN") != nullptr;  // ablation: the round-1 path
+    if (off) return 0;
+    if (a->K % BK || a->K < BK || a->N > BN || a->N < 4 || a->M < 1 || a->batch < 1) return 0;
+    if (!aligned16(a->A) || !aligned16(a->B) || a->lda % 4 || a->ldb % 4 || a->a_batch % 4 || a->b_batch % 4) return 0;
+    if (!a->b_kc && a->N % 4) return 0;
+    if (a->epi != EPI_PLAIN && (a->N != BN || !a->C)) return 0;
+    if (a->epi == EPI_PLAIN && a->N <= BN / 2) return 0;  // half of the 8 feature-side waves would multiply padding
+    if ((long)as_cdiv(a->M, 64) * a->batch > (1L << 30)) return 0;
+    LinK k{};
+    k.A = a->A; k.lda = a->lda; k.a_batch = a->a_batch;
+    k.B = a->B; k.ldb = a->ldb; k.b_batch = a->b_batch;
+    k.C = a->C; k.ldc = a->ldc; k.c_batch = a->c_batch;
+    k.bias = a->bias; k.bias_batch = a->bias_batch;
+    k.M = a->M; k.N = a->N; k.K = a->K; k.ka_valid = a->ka_valid > 0 ? a->ka_valid : a->K; k.batch = a->batch; k.act = a->act;
+    k.eps = 1e-5f;
+    static const int abl = getenv("AS_LIN_ABL") ? atoi(getenv("AS_LIN_ABL")) : 0;
+    k.abl = abl;
+    static const int stagger = getenv("AS_LIN_STAGGER") ? atoi(getenv("AS_LIN_STAGGER")) : 0;  // measured: no gain
+    k.stagger = stagger;
+    k.dbg = g_dbg; k.dbg_max = g_dbg_max;
+    k.rstd = a->rstd; k.bits = a->bits;
+    k.xhat = a->xhat; k.ldx = a->ldx; k.x_batch = a->x_batch; k.rstd_in = a->rstd_in; k.bits_in = a->bits_in;
+    if (k.ka_valid % 4) return 0;
+    if (a->epi == EPI_LNF) {
+        if (!a->rstd || !a->bits || !a->b_kc) return 0;
+        return launch<true, EPI_LNF>(k, st) == 0 ? 1 : -1;
+    }
+    if (a->epi == EPI_LNB) {
+        if (!a->xhat || !a->rstd_in || !a->bits_in || a->b_kc) return 0;
+        return launch<false, EPI_LNB>(k, st) == 0 ? 1 : -1;
+    }
+    if (a->b_kc) return launch<true, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
+    return launch<false, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
+}

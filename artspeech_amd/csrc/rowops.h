@@ -7,8 +7,9 @@
 int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st, unsigned long long* pos_bits = nullptr);
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
                      int D, hipStream_t st, const unsigned long long* relu_bits = nullptr);
+// Rpad (>= R, 0 = R): rows per head in Wf; the extra rows are written as zeros
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
-            int K, hipStream_t st);
+            int K, hipStream_t st, int Rpad = 0);
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
               float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st);
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,

@@ -124,15 +124,22 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ b,
                                                    float* __restrict__ Wf, float* __restrict__ bf, long total_rows, int R,
-                                                   int K) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                   int K, int Rpad) {
+    // Rpad >= R rows per head in Wf: rows R .. Rpad-1 are written as zeros (a reduction over them adds nothing)
+    const long prow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= total_rows) return;
-    const long head = row / R;
+    if (prow >= total_rows) return;
+    const long head = prow / Rpad;
+    const int r = (int)(prow - head * Rpad);
+    float* o = Wf + prow * K;
+    if (r >= R) {
+        for (int k = lane; k < K; k += 64) o[k] = 0.f;
+        return;
+    }
+    const long row = head * R + r;
     const float* wr = W + row * K;
     const float* gm = gamma + head * K;
     const float* bt = beta + head * K;
-    float* o = Wf + row * K;
     float s = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = wr[k];
@@ -548,9 +555,10 @@ int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, cons
     return 0;
 }
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
-            int K, hipStream_t st) {
-    const long total = (long)heads * R;
-    hipLaunchKernelGGL(fold_kernel, dim3(as_cdiv(total, 4)), dim3(256), 0, st, W, gamma, beta, b, Wf, bf, total, R, K);
+            int K, hipStream_t st, int Rpad) {
+    if (Rpad < R) Rpad = R;
+    const long total = (long)heads * Rpad;
+    hipLaunchKernelGGL(fold_kernel, dim3(as_cdiv(total, 4)), dim3(256), 0, st, W, gamma, beta, b, Wf, bf, total, R, K, Rpad);
     AS_LAUNCH_CHECK("fold");
     return 0;
 }

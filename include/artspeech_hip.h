@@ -391,6 +391,11 @@ int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * to buflen) and returns the untruncated length; it waits for the recorded events to complete. */
 void as_profile_enable(int32_t on);
 void as_profile_reset(void);
+/* Diagnostic: in-kernel cycle stamps of the fused head-layer kernels (lin_f32.hip).  buf = device array of
+ * 8 x (number of workgroups of the next launches) uint64, or NULL to switch the stamps off (the default; a kernel
+ * launched without a buffer executes no stamp).  Per workgroup: s_memtime at start, after the prologue's first wait,
+ * after the main loop, at the end; s_memrealtime at start; HW_ID and XCC_ID registers.  Never used by the product path. */
+void as_lin_debug_stamps(uint64_t* buf, int64_t max_workgroups);
 int32_t as_profile_report(char* buf, int32_t buflen);
 
 #ifdef __cplusplus
