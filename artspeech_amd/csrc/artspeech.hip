@@ -578,8 +578,13 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
                    3 * H, H, 3L * H * H, -1, T, 2));
     // embedding + layer-0 input projection through the token table
     AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
-    AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
-    AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st, 1, 0, 0, 0, slab));
+    if (E <= 256 && V <= 128) {  // embedding + input-projection gradients of layer 0 from the token sums: one small launch
+        AS_STEP("grub.dw_ih0", st, as_emb_grads(ws + w.dtab0, P + L.embedding, P + L.w_ih[0], V, 6 * H, E, G + L.w_ih[0], G + L.b_ih[0],
+                                                G + L.embedding, st));
+    } else {
+        AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
+        AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st, 1, 0, 0, 0, slab));
+    }
     if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side stream's work
     return 0;
 }

@@ -23,6 +23,8 @@
 // normalize_fwd_kernel / normalize_bwd_kernel (rowops.hip) do, reading the GEMM result from LDS instead of HBM.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "gemm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,7 +39,8 @@ struct LinK {
     const float* B; long ldb, b_batch;
     float* C; long ldc, c_batch;
     const float* bias; long bias_batch;
-    int M, N, K, ka_valid, batch, act, tiles_m;
+    int M, N, K, ka_valid, batch, act;
+    int n_big, big_per_batch, big_per_batch_rows, small_per_batch;   // tiles of 64 rows first, then tiles of 32 rows (see launch())
     int stagger;
     unsigned long long* dbg; long dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps), normally null
     int abl;  // diagnostic (AS_LIN_ABL): 1 = return before the epilogue, 2 = no DMA after the prologue
@@ -94,8 +97,18 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     constexpr int RING = NBUF * TILE, EPIT = 32 * BN;
     __shared__ __attribute__((aligned(16))) float smem[RING > EPIT ? RING : EPIT];
 
-    const int tm = blockIdx.x % g.tiles_m, bz = blockIdx.x / g.tiles_m;
-    const int m0 = tm * BM;
+    // tile list: the 64-row tiles of every head first, then 32-row tiles over the remaining rows of every head
+    int bz, m0, tm_eff;
+    if ((int)blockIdx.x < g.n_big) {
+        bz = blockIdx.x / g.big_per_batch;
+        m0 = (blockIdx.x - bz * g.big_per_batch) * BM;
+        tm_eff = TM;
+    } else {
+        const int j = blockIdx.x - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        tm_eff = 1;
+    }
     const float* __restrict__ A = g.A + (long)bz * g.a_batch;
     const float* __restrict__ B = g.B + (long)bz * g.b_batch;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,6 +170,8 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
         for (int i = 0; i < nk * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
     }
     const int swz = (l31 >> 2) & 3;   // rows i * 32 + l31 and wave * 32 + l31 share it (32 = 0 mod 16)
+    // two k-tiles in flight; the older one is retired with vmcnt(3).  (A 2-slot ring with three workgroups per CU was no
+    // faster: 108-118 us against 108-114 for head GEMM 2.)
     issue(0);
     if (nk > 1) issue(1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -168,29 +183,34 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
         const float* tile = smem + (kt % NBUF) * TILE;
         const float* a_s = tile + l31 * BK;
         const float* b_s = tile + BK * BM;
+        auto body = [&](auto tmc) {
+            constexpr int TMC = decltype(tmc)::value;
 #pragma unroll
-        for (int cc = 0; cc < BK / 8; ++cc) {
-            const int slot = ((2 * cc + lh) ^ swz) * 4;
-            float4 av[TM];
+            for (int cc = 0; cc < BK / 8; ++cc) {
+                const int slot = ((2 * cc + lh) ^ swz) * 4;
+                float4 av[TMC];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + slot);
-            float bv[4];
-            if (B_KC) {
-                const float4 t = *reinterpret_cast<const float4*>(b_s + (wave * 32 + l31) * BK + slot);
-                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-            } else {
+                for (int i = 0; i < TMC; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + slot);
+                float bv[4];
+                if (B_KC) {
+                    const float4 t = *reinterpret_cast<const float4*>(b_s + (wave * 32 + l31) * BK + slot);
+                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
-            }
+                    for (int j = 0; j < 4; ++j) bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float a = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[i], 0, 0, 0);
+                    for (int i = 0; i < TMC; ++i) {
+                        const float a = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[i], 0, 0, 0);
+                    }
                 }
             }
-        }
+        };
+        if (tm_eff == TM) body(std::integral_constant<int, TM>{});
+        else body(std::integral_constant<int, 1>{});
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -244,6 +264,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {   // 32 rows at a time through 32 KB of LDS
+        if (i >= tm_eff) break;
         if (i > 0) lds_barrier();    // the previous block's rows are all read
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -311,11 +332,27 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Tile list.  Two workgroups per CU = 512 slots; a launch of T equal tiles takes ceil(T / 512) rounds, and the head
+// layers' 1100 tiles of 64 rows were 3 rounds of which the last held 76 tiles (measured: 31 us of a 118 us launch with
+// 180 CUs idle).  So: as many 64-row tiles as fill whole rounds, dispatched first, then the remaining rows as 32-row
+// tiles (half the matrix work each), which pack the last round about half as high.
 template <bool B_KC, int EPI>
 int launch(const LinK& k, hipStream_t st) {
     LinK kk = k;
-    kk.tiles_m = as_cdiv(k.M, 64);
-    hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI>), dim3((unsigned)((long)kk.tiles_m * k.batch)), dim3(NT), 0, st, kk);
+    constexpr int slots = 512;
+    const long units = (long)as_cdiv(k.M, 64) * k.batch;      // work in 64-row tiles
+    const long rounds = units / slots;
+    static const bool all_big = getenv("AS_LIN_ALLBIG") != nullptr;  // ablation: 64-row tiles only (+ a ragged end)
+    int x = (int)(rounds * slots / k.batch);                    // 64-row tiles per head that fill whole rounds
+    if (x > k.M / 64 || all_big) x = k.M / 64;
+    const int rest = k.M - x * 64;
+    kk.big_per_batch = x > 0 ? x : 1;
+    kk.big_per_batch_rows = x * 64;
+    kk.n_big = x * k.batch;
+    kk.small_per_batch = as_cdiv(rest, 32);
+    const long total = (long)kk.n_big + (long)kk.small_per_batch * k.batch;
+    if (kk.small_per_batch == 0) kk.small_per_batch = 1;
+    hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI>), dim3((unsigned)total), dim3(NT), 0, st, kk);
     AS_LAUNCH_CHECK("as_lin_f32");
     return 0;
 }

@@ -14,6 +14,9 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
               float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st);
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
                     hipStream_t st, float* scratch = nullptr, long scratch_floats = 0);
+// dW [C][E] = dtab^T . emb, db [C] = column sums of dtab, demb [V][E] = dtab . W   (dtab [V][C], emb [V][E], W [C][E])
+int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int C, int E, float* dW, float* db, float* demb,
+                 hipStream_t st);
 int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
                    hipStream_t st);
 int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st);

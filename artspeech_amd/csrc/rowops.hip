@@ -270,9 +270,126 @@ __global__ __launch_bounds__(256) void token_segsum_reduce_kernel(const float* _
                                                                   float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // eight chunk partials in flight at a time (a chain of dependent loads would cost a memory round trip per chunk); the
+    // order of the additions is fixed, so the result is reproducible
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long)c * n + i];
+    int c = 0;
+    for (; c + 7 < chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < chunks; ++c) s += part[(long)c * n + i];
     out[i] = s;
+}
+
+// Column-sliced form for wide rows (C a multiple of 64, V <= 128): grid (C / 64, chunks), one workgroup = 64 columns x one
+// chunk of rows.  Four row lanes (threadIdx / 64) walk the chunk with stride 4 and add into four private [V][64] tables in
+// LDS (1 KB x V in all), which are combined in a fixed order at the end: no atomics, bitwise reproducible, one read of x.
+// 192 workgroups at rows = 6400, C = 768 instead of 3375 that each compact a token chunk and touch a handful of rows.
+__global__ __launch_bounds__(256) void token_segsum_cols_kernel(const float* __restrict__ x, const int64_t* __restrict__ tokens,
+                                                                long tok_stride, int T, long rows, int C, int V, int rows_per_chunk,
+                                                                float* __restrict__ part) {
+    extern __shared__ float tab[];   // [4][V][64]
+    const int c64 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c64;
+    for (int i = threadIdx.x; i < 4 * V * 64; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    float* mine = tab + (long)rl * V * 64 + c64;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    // (utterance, frame) of this lane's current row, advanced by 4 rows per visit: no 64-bit division per row
+    long r = r0 + rl;
+    long tb = r / T;
+    int tt = (int)(r - tb * T);
+    auto next_tok = [&]() {
+        const int v = (int)tokens[tb * tok_stride + tt];
+        tt += 4;
+        while (tt >= T) { tt -= T; ++tb; }
+        return v;
+    };
+    for (; r + 28 < r1; r += 32) {   // eight rows of this lane in flight: the kernel lives on memory latency
+        float xv[8];
+        int tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xv[u] = x[(r + 4 * u) * C + col];
+            tv[u] = next_tok();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mine[tv[u] * 64] += xv[u];
+    }
+    for (; r < r1; r += 4) mine[next_tok() * 64] += x[r * C + col];
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * 64; i += 256) {
+        const float sum = ((tab[i] + tab[V * 64 + i]) + tab[2 * V * 64 + i]) + tab[3 * V * 64 + i];
+        part[((long)blockIdx.y * V + (i >> 6)) * C + blockIdx.x * 64 + (i & 63)] = sum;
+    }
+}
+
+// Gradients of the embedding / layer-0 input projection from the per-token sums dtab [V][C] (C = 2 * 3H gate rows):
+//   dW[c][e] = sum_v dtab[v][c] * emb[v][e],  db[c] = sum_v dtab[v][c]      blocks [0, C / 4): one wave per row c
+//   demb[v][e] = sum_c dtab[v][c] * W[c][e]                                  blocks [C / 4, C / 4 + V): one block per token
+// Two 64 x 64-tile GEMM launches under reductions of 45 and 768 took 10 + 21 us on the step's critical tail; this is one
+// launch of a few microseconds.  E <= 256.
+__global__ __launch_bounds__(1024) void emb_grads_kernel(const float* __restrict__ dtab, const float* __restrict__ emb,
+                                                         const float* __restrict__ W, int V, int C, int E,
+                                                         float* __restrict__ dW, float* __restrict__ db, float* __restrict__ demb) {
+    // Everything is staged through LDS with all loads of a phase in flight at once: these are tiny reductions whose time is
+    // the number of dependent memory round trips, not bytes or FLOPs.
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < C / 16) {
+        // 16 rows c of dW: stage emb [V][E] and dtab[:, c0 .. c0+15], then thread (c, e) sums over v from LDS
+        float* s_emb = sm;                 // V * E
+        float* s_d = sm + (long)V * E;     // V * 16
+        const int c0 = blockIdx.x * 16;
+        for (int i = tid; i < V * E; i += 1024) s_emb[i] = emb[i];
+        for (int i = tid; i < V * 16; i += 1024) s_d[i] = dtab[(long)(i >> 4) * C + c0 + (i & 15)];
+        __syncthreads();
+        for (int o = tid; o < 16 * E; o += 1024) {
+            const int cc = o / E, e = o - cc * E;
+            float a = 0.f;
+            for (int v = 0; v < V; ++v) a += s_d[v * 16 + cc] * s_emb[v * E + e];
+            dW[(long)(c0 + cc) * E + e] = a;
+        }
+        if (tid < 16) {
+            float bsum = 0.f;
+            for (int v = 0; v < V; ++v) bsum += s_d[v * 16 + tid];
+            db[c0 + tid] = bsum;
+        }
+        return;
+    }
+    // one block per token v: demb[v][e] = sum_c dtab[v][c] * W[c][e]; thread (part, e): c = part, part + P, ... with 16 loads
+    // of W in flight, partials combined through LDS in a fixed order
+    const int v = blockIdx.x - C / 16;
+    if (v >= V) return;
+    float* s_row = sm;          // C
+    float* s_part = sm + C;     // P * E
+    for (int i = tid; i < C; i += 1024) s_row[i] = dtab[(long)v * C + i];
+    __syncthreads();
+    const int P = 1024 / E > 0 ? 1024 / E : 1;   // parts (E <= 1024)
+    const int e = tid % E, part = tid / E;
+    if (part < P) {
+        float a = 0.f;
+        int c = part;
+        for (; c + 15 * P < C; c += 16 * P) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = W[(long)(c + u * P) * E + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += s_row[c + u * P] * wv[u];
+        }
+        for (; c < C; c += P) a += s_row[c] * W[(long)c * E + e];
+        s_part[part * E + e] = a;
+    }
+    __syncthreads();
+    if (tid < E) {
+        float a = 0.f;
+        for (int p = 0; p < P; ++p) a += s_part[p * E + tid];
+        demb[(long)v * E + tid] = a;
+    }
 }
 
 // ---- out[m][:] = table[token(m)][:] --------------------------------------------------------------
@@ -570,6 +687,18 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
 }
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
                     hipStream_t st, float* scratch, long scratch_floats) {
+    if (scratch && C % 64 == 0 && V <= 128 && rows >= 1024) {   // wide rows: column-sliced single pass + ordered reduce
+        const int chunks = (int)as_cdiv(rows, 128);   // 32 rows per row lane: four batches of eight loads
+        const int rpc = (int)as_round_up(as_cdiv(rows, chunks), 4);
+        if ((long)chunks * V * C <= scratch_floats) {
+            hipLaunchKernelGGL(token_segsum_cols_kernel, dim3(C / 64, as_cdiv(rows, rpc)), dim3(256), (size_t)4 * V * 64 * sizeof(float), st, x,
+                               tokens, tok_stride, T, rows, C, V, rpc, scratch);
+            hipLaunchKernelGGL(token_segsum_reduce_kernel, dim3(as_cdiv((long)V * C, 256)), dim3(256), 0, st, scratch, (long)V * C,
+                               as_cdiv(rows, rpc), out);
+            AS_LAUNCH_CHECK("token_segsum");
+            return 0;
+        }
+    }
     const int chunks = as_cdiv(rows, 256);
     if (scratch && chunks > 1 && chunks <= 65535 && (long)chunks * V * C <= scratch_floats) {
         hipLaunchKernelGGL(token_segsum_part_kernel, dim3(V, as_cdiv(C, 256), chunks), dim3(256), 0, st, x, tokens, tok_stride, T, rows,
@@ -580,6 +709,15 @@ int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int 
         hipLaunchKernelGGL(token_segsum_kernel, dim3(V, as_cdiv(C, 256)), dim3(256), 0, st, x, tokens, tok_stride, T, rows, C, out);
     }
     AS_LAUNCH_CHECK("token_segsum");
+    return 0;
+}
+int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int C, int E, float* dW, float* db, float* demb,
+                 hipStream_t st) {
+    AS_REQUIRE(C % 16 == 0 && E <= 256 && V <= 128, AS_ERR_UNSUPPORTED, "emb_grads: V=%d C=%d E=%d", V, C, E);
+    const long f1 = (long)V * E + (long)V * 16, f2 = (long)C + (long)(1024 / E) * E;
+    const size_t shm = (size_t)(f1 > f2 ? f1 : f2) * sizeof(float);
+    hipLaunchKernelGGL(emb_grads_kernel, dim3(C / 16 + V), dim3(1024), shm, st, dtab, emb, W, V, C, E, dW, db, demb);
+    AS_LAUNCH_CHECK("emb_grads");
     return 0;
 }
 int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,

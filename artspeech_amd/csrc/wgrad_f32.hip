@@ -22,7 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BK = 32, NT = 512, NBUF = 3;
+constexpr int BM = 128, NT = 512, NBUF = 3;
+constexpr int KALIGN = 32;   // reduction chunks are multiples of both k-tile depths
 
 struct WgradK {
     const float* A; const float* B; float* C;
@@ -42,19 +43,27 @@ struct WgradK {
 };
 
 // LDS-DMA helper: one wave-instruction copies 64 x 16 B from per-lane global addresses to 1 KiB of LDS starting at the
-// wave-uniform `dst` (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt)
+// wave-uniform `dst` (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt).  Inline asm: with the builtin hipcc
+// may put an s_waitcnt vmcnt(0) in front of the next ds_read (it did in the BK = 16 instantiation), which drains the ring.
 __device__ __forceinline__ void glds16(const float* src, float* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    unsigned keep;
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds)
+                 : "memory");
 }
 
-template <int BN>
-__global__ __launch_bounds__(NT, 2) void wgrad_f32_kernel(WgradK g) {
+// BK = 32: one workgroup per CU (144 KB of LDS at BN = 256, two k-tiles = 96 KB in flight).  BK = 16: 72 KB, two workgroups
+// per CU -- the partner's MFMAs cover this one's barriers, prologue and epilogue.
+template <int BN, int BK>
+__global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK g) {
     constexpr int WN = BN / 4, TN = WN / 32, TM = 2;   // 2 x 4 waves; a wave owns 64 rows x WN columns
     constexpr int TILE = BK * (BM + BN);                // floats per ring slot: A image [BK][BM] then B image [BK][BN]
     constexpr int PA = BK * BM / 256 / 8;               // 1-KiB DMA pieces of A per wave and k-tile (2)
     constexpr int PB = BK * BN / 256 / 8;               // ... of B (4 at BN = 256, 2 at BN = 128)
     constexpr int RB = 256 / BN;                        // B rows per piece (1 or 2)
+    constexpr int CSR = BK / 4;                         // rows of a k-tile each of the four colsum row groups adds
     // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain the DMAs before every read)
     __shared__ __attribute__((aligned(16))) float smem[NBUF * TILE];
 
@@ -124,9 +133,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_f32_kernel(WgradK g) {
         const float* a_s = tile + wm * 64 + l31;
         const float* b_s = tile + BK * BM + wn * WN + l31;
         if (do_cs) {
-            const float* c_s = tile + (tid >> 7) * 8 * BM + (tid & 127);
+            const float* c_s = tile + (tid >> 7) * CSR * BM + (tid & 127);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) cs += c_s[r * BM];
+            for (int r = 0; r < CSR; ++r) cs += c_s[r * BM];
         }
         // operands of k-step kk + 1 are read before the MFMAs of k-step kk are issued (their LDS latency hides behind them)
         float av[2][TM], bv[2][TN];
@@ -242,7 +251,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     static const bool off = getenv("AS_NO_WGRAD") != nullptr;  // ablation: the general kernel
     if (off) return 0;
-    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % BK || g->b_kT > 0 || g->act != 0 || g->bias) return 0;
+    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->b_kT > 0 || g->act != 0 || g->bias) return 0;
     if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return 0;
     const bool grouped = g->a_off || g->b_off || g->c_off;
     if (!grouped && (g->a_batch % 4 || g->b_batch % 4)) return 0;
@@ -269,7 +278,8 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     if (!all_shapes && tiles * (g->K / 256) < 256) return 0;
     // split K so that the launch has about `target` workgroups (one per CU and round); cost model in DESIGN.md 5
     static const int target_env = getenv("AS_WGRAD_TARGET") ? atoi(getenv("AS_WGRAD_TARGET")) : 0;
-    const int cus = g->cu_budget > 0 ? g->cu_budget : 256;
+    static const int bk = getenv("AS_WGRAD_BK") ? atoi(getenv("AS_WGRAD_BK")) : 32;
+    const int cus = (g->cu_budget > 0 ? g->cu_budget : 256) * (bk == 16 ? 2 : 1);   // slots: two workgroups per CU at BK = 16
     long S = 1;
     const long per = (long)g->batch * g->M * g->N, per_cs = g->colsum ? (long)g->batch * g->M : 0;
     if (g->splitk_ws && tiles < cus) {
@@ -277,10 +287,10 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
             S = target_env / tiles;
         } else {
             // time ~ rounds * k-steps per workgroup * c1 + slab traffic; c1 = us per k of one 128 x bn tile on one CU
-            const double c1 = (bn == 256 ? 256.0 : 128.0) / 2400.0, c2 = 8.0 / 4.0e6;  // write + read of a float at ~4 TB/s
+            const double c1 = (bn == 256 ? 256.0 : 128.0) / 2400.0 * (bk == 16 ? 2 : 1), c2 = 8.0 / 4.0e6;  // write + read of a float at ~4 TB/s
             double best = 1e30;
             for (long s = 1; s <= 64 && s * 128 <= g->K; ++s) {
-                const long chunk = as_round_up(as_cdiv(g->K, s), BK);
+                const long chunk = as_round_up(as_cdiv(g->K, s), KALIGN);
                 const long rounds = (tiles * s + cus - 1) / cus;
                 const double cost = rounds * chunk * c1 + (s > 1 ? s * (per + per_cs) * c2 : 0.0);
                 if (cost < best - 1e-9) best = cost, S = s;
@@ -290,7 +300,7 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
         if (S * (per + per_cs) > g->splitk_ws_floats) S = g->splitk_ws_floats / (per + per_cs);
         if (S < 1) S = 1;
     }
-    k.kchunk = (int)as_round_up(as_cdiv(g->K, S), BK);
+    k.kchunk = (int)as_round_up(as_cdiv(g->K, S), KALIGN);
     k.splitk = as_cdiv(g->K, k.kchunk);
     if (k.splitk > 1) {
         k.slab = g->splitk_ws;
@@ -299,8 +309,13 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     k.ncombos = (long)g->batch * k.splitk * k.tiles_n;
     k.per_xcd = (int)((k.ncombos * k.tiles_m + 7) / 8);
     const dim3 grid((unsigned)(8 * k.per_xcd));
-    if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256>), grid, dim3(NT), 0, st, k);
-    else hipLaunchKernelGGL((wgrad_f32_kernel<128>), grid, dim3(NT), 0, st, k);
+    if (bk == 16) {
+        if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256, 16>), grid, dim3(NT), 0, st, k);
+        else hipLaunchKernelGGL((wgrad_f32_kernel<128, 16>), grid, dim3(NT), 0, st, k);
+    } else {
+        if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256, 32>), grid, dim3(NT), 0, st, k);
+        else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(NT), 0, st, k);
+    }
     AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
     if (k.splitk > 1) {
         const long threads = per / 4 + per_cs;

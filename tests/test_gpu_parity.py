@@ -403,6 +403,36 @@ def test_artspeech_vs_oracle_ragged_full_width(dev):
         assert_grad_close(v.cpu().numpy(), og[k], f"ragged full width vs oracle: {k}")
 
 
+def test_artspeech_vs_oracle_more_than_1024_frames(dev):
+    """B * T = 1280 frames: the sizes at which the embedding / layer-0 gradients take the column-sliced token sums
+    (token_segsum_cols_kernel) and the fused linears their mixed 64 / 32-row tile list.  Every gradient against the oracle."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(4)
+    A = 2
+    model = ArtSpeech(45, A)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, T = 8, 160
+    lengths = np.array([160, 151, 133, 97, 64, 30, 7, 1])
+    rng = np.random.RandomState(1)
+    x = rng.randint(1, 45, (B, T))
+    tgt = rng.rand(B, T, A, 2, 50).astype(np.float32)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    loss = masked_euclidean_loss(out, T_(tgt, dev), lengths)
+    loss.backward()
+    o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
+    assert_close(out.detach().cpu().numpy(), o_out, what="contours")
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    og = O.artspeech_bwd(o_dout, cache, A)
+    for k, v in model.named_grad_views().items():
+        assert_grad_close(v.cpu().numpy(), og[k], f"1280 frames vs oracle: {k}")
+
+
 # ------------------------------------------------------------------------------------------- metrics
 def test_metrics_match_reference_fixture(dev):
     from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance

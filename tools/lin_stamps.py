@@ -22,7 +22,7 @@ x = torch.relu(torch.randn(rows, H, device=dev))
 out = torch.empty(rows, A, 2, N, device=dev)
 ws = torch.empty(L.as_head_workspace_floats(C.byref(dims), rows), device=dev)
 st = _lib.stream_ptr()
-nwg = 1100
+nwg = 1400
 for _ in range(3):
     _lib.check(L.as_head_fwd(C.byref(dims), C.byref(lay), _lib.ptr(P), _lib.ptr(x), rows, _lib.ptr(out), _lib.ptr(ws), 1, st))
 stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
@@ -36,7 +36,10 @@ pro, loop, epi, tot = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s
 r0 = s[:, 4].min()
 start_us, end_us = (s[:, 4] - r0) / 100.0, (s[:, 6] - r0) / 100.0     # s_memrealtime: 100 MHz, one clock for the chip
 print("per workgroup, shader cycles (s_memtime differences) and wall microseconds (s_memrealtime), launch order")
-for lo in (0, 256, 512, 768, 1024):
+live = s[:, 3] > 0
+nwg = int(live.sum())
+print('workgroups stamped:', nwg)
+for lo in range(0, nwg, 256):
     hi = min(lo + 256, nwg)
     sl = slice(lo, hi)
     print(f"wg {lo:4d}-{hi - 1:4d}: start {np.median(start_us[sl]):6.1f} us  end {np.median(end_us[sl]):6.1f} us | prologue {np.median(pro[sl]):7.0f}  "
