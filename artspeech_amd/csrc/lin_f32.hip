@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < g.M) {
+                    if (i < tm_eff && row < g.M) {   // (a 32-row tile owns only its first row block)
                         float v = acc[i][r] + bj;
                         if (g.act == 1) v = fmaxf(v, 0.f);
                         else if (g.act == 2) v = as_sigmoid(v);

@@ -30,10 +30,10 @@ def golden():
 WORST = {}
 
 
-def assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=2e-5, atol_abs=0.0):
+def assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=1e-5, atol_abs=0.0):
     """Element-wise gradient check: |got - ref| <= rtol * |ref| + atol_frac * max|ref| for every element (the absolute floor
     scales with the tensor because fp32 accumulation error does not shrink with the element it lands on).  Measured worst
-    case on the fixtures is ~4e-6 of max|ref|; the message carries the observed figure."""
+    case over all fixtures is 2.5e-6 of max|ref| (profiles/r02_parity_worst_errors.json); the message carries the observed figure."""
     a, b = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     scale = max(float(np.abs(b).max()), 1e-30)
