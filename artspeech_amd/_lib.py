@@ -102,6 +102,7 @@ PROTOTYPES = {
     "as_intersect_semipolar_grid": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
     "as_artspeech_wait_head_grads": (_I32, [_P, _P]),
     "as_lin_debug_stamps": (None, [_P, _I64]),
+    "as_gru_debug_stamps": (None, [_P]),
     "as_profile_enable": (None, [_I32]),
     "as_profile_reset": (None, []),
     "as_profile_report": (_I32, [C.c_char_p, _I32]),

@@ -282,9 +282,16 @@ template <int H>
 __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ gates, const float* __restrict__ w_hh,
                                                             const int* __restrict__ lengths, int T, float* __restrict__ dgi,
-                                                            float* __restrict__ dgh) {
+                                                            float* __restrict__ dgh, unsigned long long* __restrict__ dbg) {
     constexpr int NT = 4 * H;
     constexpr int VL = 3 * H / 16;            // gate rows per lane
+    // diagnostic (as_gru_debug_stamps): shader-clock and 100 MHz wall-clock stamps around the recurrence of this workgroup;
+    // dbg is null in every product launch and no stamp executes then
+    unsigned long long t_start = 0, r_start = 0;
+    if (dbg != nullptr && threadIdx.x == 0) {
+        t_start = __builtin_amdgcn_s_memtime();
+        r_start = __builtin_amdgcn_s_memrealtime();
+    }
     constexpr int VW = VL % 4 == 0 ? 4 : 2;   // floats per LDS read
     constexpr int NCH = VL / VW;              // LDS reads per lane per step
     __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
@@ -406,6 +413,13 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         fr += dt;
         // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
     }
+    if (dbg != nullptr && threadIdx.x == 0) {
+        unsigned long long* d = dbg + 4L * (blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = __builtin_amdgcn_s_memtime() - t_start;
+        d[1] = __builtin_amdgcn_s_memrealtime() - r_start;
+        d[2] = (unsigned long long)len;
+        d[3] = r_start;
+    }
 }
 
 // Lanes per hidden unit.  Both layouts are built; measured at H = 128, B = 32, T = 200 (tools/bench_gru.py):
@@ -415,6 +429,9 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
 constexpr int lpu_of(int) { return 4; }
 
 }  // namespace
+
+static unsigned long long* g_gru_dbg = nullptr;
+extern "C" void as_gru_debug_stamps(uint64_t* buf) { g_gru_dbg = (unsigned long long*)buf; }
 
 static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
                           const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, int nd, void* stream) {
@@ -470,7 +487,7 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
         hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
                            T, dgi, dgh);                                                                                      \
     else                                                                                                                      \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh)
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh, g_gru_dbg)
     switch (H) {
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
