@@ -379,3 +379,37 @@ def test_key_major_mask_is_transposed_padded_and_cached():
     m[0, 0, 0] = 7.0                                      # in-place change bumps the version
     mt2 = ops._key_major_mask(m, Tk, T)
     assert mt2 is not mt and mt2[0, 0, 0] == 7.0
+
+
+def test_bench_self_launch_builds_a_child_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun: the parent spawns `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a CHILD (subprocess, never exec), falls back to the
+    shared-card gloo rehearsal when fewer cards than ranks are visible, and refuses a rehearsal that would put too many
+    processes on one card.  No GPU is touched: device_count() is the only torch.cuda call on this path."""
+    import importlib
+    import sys as _sys
+    import types
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    args = types.SimpleNamespace(gpus=2)
+    assert bench.self_launch(args) == 7                       # the children's exit code is the parent's
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert calls["env"]["ARTSPEECH_DIST_BACKEND"] == "gloo"   # one card, two ranks: rehearsal
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    args.gpus = 8
+    bench.self_launch(args)
+    assert "ARTSPEECH_DIST_BACKEND" not in calls["env"] or calls["env"].get("ARTSPEECH_DIST_BACKEND") == os.environ.get("ARTSPEECH_DIST_BACKEND")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit):
+        bench.self_launch(args)                               # 8 ranks on one card: refused
