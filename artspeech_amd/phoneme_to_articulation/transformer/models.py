@@ -21,6 +21,7 @@ import math
 import os
 
 import torch
+import torch.utils.checkpoint
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -377,7 +378,17 @@ class ArtSpeechTransformer(nn.Module):
         x = F.dropout(emb + self.pe[0, :T].view(1, T, 1, d), self.dropout, train)            # positional encoding per channel
         x = x.permute(2, 0, 1, 3).reshape(A, R, d)                                             # channel-major
         mem_hat = Normalize.apply(memory)[None] if memory_kv is None else None                 # shared by every cross block
+        # ARTSPEECH_CHECKPOINT_LAYERS=1 (or model.checkpoint_layers = True): keep only each decoder layer's INPUT for the
+        # backward and recompute the layer's forward there (every op is an autograd Function, so torch.utils.checkpoint
+        # applies as is): about one sixth of the activation memory for one extra forward of the decoder
+        ckpt = (getattr(self, "checkpoint_layers", False) or os.environ.get("ARTSPEECH_CHECKPOINT_LAYERS") == "1") and \
+            torch.is_grad_enabled() and memory_kv is None and not last_only
         for l in range(self.num_layers):
+            if ckpt:
+                def run(x_, mem_, l=l):
+                    return self._decoder_layer(l, x_, mem_, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, B)
+                x = torch.utils.checkpoint.checkpoint(run, x, mem_hat, use_reentrant=False)
+                continue
             x = self._decoder_layer(l, x, mem_hat, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, B,
                                     mem_kv=None if memory_kv is None else memory_kv[l],
                                     last_only=last_only and l == self.num_layers - 1)

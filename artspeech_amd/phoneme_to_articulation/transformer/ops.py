@@ -262,9 +262,10 @@ class Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dctx):
-        if len(ctx.saved_tensors) == 5:
-            return Attention._backward_key_major(ctx, dctx)
-        Q, K, V, P = ctx.saved_tensors
+        saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
+        if len(saved) == 5:
+            return Attention._backward_key_major(ctx, dctx, saved)
+        Q, K, V, P = saved
         B, heads, scale, zq, zk, zs = ctx.meta
         G, R, d = Q.shape
         Rk = K.shape[1]
@@ -283,11 +284,11 @@ class Attention(torch.autograd.Function):
         return dQ, dK, dV, None, None, None, None
 
 
-def _attention_backward_key_major(ctx, dctx):
+def _attention_backward_key_major(ctx, dctx, saved):
     """Backward of the fused forward: the same five products as the unfused path, on the KEY-major probabilities
     P^T [Z][Tk][T] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
     second pass over the scores."""
-    Q, K, V, Pt, out = ctx.saved_tensors
+    Q, K, V, Pt, out = saved
     B, heads, scale = ctx.meta[:3]
     G, R, d = Q.shape
     Rk = K.shape[1]

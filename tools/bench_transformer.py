@@ -76,6 +76,19 @@ def run(B=32, T=200, iters=3, dev=None, log=print):
                       "frac_of_157.3": round(3 * flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 3), "loss": round(float(loss), 5),
                       "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
     log(f"transformer fwd+bwd B={B} T={T}: {res['fwd_bwd']}")
+    if os.environ.get("ARTSPEECH_BENCH_CHECKPOINT"):   # the same step with per-layer activation checkpointing
+        model.checkpoint_layers = True
+        torch.cuda.reset_peak_memory_stats()
+        loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        res["fwd_bwd_checkpointed"] = {"ms_per_step": round(dt * 1e3, 2), "loss": round(float(loss), 5),
+                                       "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+        log(f"transformer fwd+bwd, decoder layers checkpointed: {res['fwd_bwd_checkpointed']}")
     del model
     torch.cuda.empty_cache()
     return res
