@@ -8,12 +8,18 @@
 //     different XCDs, i.e. different L2s -- the launch moves 2-4x its operand bytes through the fabric.  Here ONE workgroup
 //     owns a 128 x 256 (or 128 x 128) output tile, so for the head layers (N <= 256) a B panel is fetched by the M-tiles of
 //     one XCD only (the block index -> work map puts the M-tiles of a (batch, k-slab, n-tile) on one XCD, back to back);
-//   * 8 waves (2 per SIMD), each with a 64 x 64 (64 x 32) sub-tile = 4 (2) MFMAs per 2 + 2 (2 + 1) operand reads;
-//   * LDS double buffer with ONE barrier per 16-deep k-tile; the image is a straight copy of the global rows ([k][m]),
-//     which already is what an MFMA operand wants (lane i reads column i of row k: conflict-free ds_read_b32);
-//   * the fused bias gradient (column sums of A) comes out of the staging registers, not out of extra LDS reads;
+//   * 8 waves (2 per SIMD), each with a 64 x 64 (64 x 32) sub-tile = 4 (2) MFMAs per 2 + 2 (2 + 1) operand reads, the reads
+//     of k-step s + 1 issued ahead of the MFMAs of k-step s;
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4) in a ring of three 32-deep k-tiles: two k-tiles (96 KB at
+//     BN = 256) are in flight per CU while the third is multiplied; a counted s_waitcnt vmcnt + ONE raw barrier per k-tile.
+//     The image is a straight copy of the global rows ([k][m]), which already is what an MFMA operand wants (lane i reads
+//     column i of row k: conflict-free ds_read_b32).  (First version: register staging, one 16-deep k-tile in flight -- it
+//     ran at the latency of its own loads: loads-only ablation 766 us, MFMA-only 874 us, both 1030 us on the grouped
+//     transformer shape.  A second register set spilled.)
+//   * the fused bias gradient (column sums of A) costs 8 LDS reads per thread and k-tile, combined in a fixed order;
 //   * deterministic split-K over slabs with a wide reduce kernel (fixed summation order: results do not depend on the
-//     order in which workgroups are scheduled).
+//     order in which workgroups are scheduled); the split comes from a small cost model over whole rounds of workgroups
+//     and slab traffic, for the number of CUs the caller expects to be free (as_gemm.cu_budget).
 #include <cstdlib>
 
 #include "gemm_internal.h"
