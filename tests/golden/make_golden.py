@@ -544,6 +544,111 @@ def load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_met
     return ref_eval, ref_train
 
 
+def gen_artspeech_c2(models, p2a_metrics, helpers):
+    """BASELINE configs[1] at FULL size through the reference itself: ArtSpeech(45, 11), B=32, T=200, parity lengths
+    linspace(200, 60, 32).  Weights (7.5 MB) and targets (28 MB) are too big for a fixture: both are functions
+    of torch's seeded CPU generator, which the test re-runs (seed-for-seed identical initialisation is itself a tested
+    contract, tests/test_host.py); the fixture holds checksums of the regenerated inputs, the loss, slices of the
+    contours, and per-tensor norms / slices of every gradient."""
+    torch.manual_seed(0)
+    V, A, E, H, N, B, T = 45, 11, 64, 128, 50, 32, 200
+    model = models.ArtSpeech(V, A, embed_dim=E, hidden_size=H, n_samples=N)
+    x = torch.randint(1, V, (B, T))
+    lengths = torch.linspace(200, 60, B).int()
+    tgt = torch.rand(B, T, A, 2, N)
+    for i, l in enumerate(lengths):
+        x[i, l:] = 0
+        tgt[i, l:] = 0
+    out = model(x, lengths)
+    loss = masked_mean_loss(p2a_metrics.EuclideanDistance("none"), helpers.make_padding_mask, out, tgt, lengths)
+    loss.backward()
+    pos = [(0, 0), (0, 199), (5, 100), (17, 3), (31, 59), (31, 60), (12, 150)]
+    arrays = dict(
+        cfg=np.array([V, A, E, H, N, B, T], dtype=np.int64), lengths=lengths.numpy(), positions=np.array(pos),
+        x_sum=np.int64(x.sum().item()), tgt_sum=np.float64(tgt.double().sum().item()),
+        w_sum=np.float64(sum(p.double().sum().item() for p in model.parameters())),
+        loss=np.float64(loss.item()), out_sum=np.float64(out.double().sum().item()),
+        out_slices=np.stack([out[b, t].detach().numpy() for b, t in pos]),
+    )
+    for k, p in model.named_parameters():
+        g = p.grad
+        arrays["gnorm." + k] = np.float64(g.double().norm().item())
+        arrays["gmax." + k] = np.float64(g.abs().max().item())
+        arrays["gslice." + k] = g.reshape(-1)[:: max(1, g.numel() // 257)][:257].numpy().copy()
+    save("artspeech_c2_full", **arrays)
+    return dict(loss=float(loss), out_sum=float(out.double().sum()))
+
+
+C4_SLICE = 33   # strided gradient elements kept per tensor
+
+
+def c4_case(model_cls, dataset_collate, seed=0):
+    """The seeded recipe of the full-width transformer case (shared text with tests/test_gpu_transformer.py, which re-runs it
+    with the build's classes): BASELINE configs[3]'s model (V=45, A=11, d=256, 4 heads, 6 layers, 100 features) on a
+    two-utterance ragged batch of T=200.  Decoder layers are deep copies of one layer at construction; layer l's tensors are
+    scaled by 1 + 0.01 (l + 1) (by state_dict key, so the order of parameters does not matter) to tell the layers apart."""
+    torch.manual_seed(seed)
+    V, A, d, heads, L, nf = 45, 11, 256, 4, 6, 100
+    model = model_cls(V, A, embed_dim=d, num_heads=heads, num_layers=L, num_feat=nf)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.startswith("decoder.layers.") and v.dtype.is_floating_point:
+                v.mul_(1.0 + 0.01 * (int(k.split(".")[2]) + 1))
+    model.load_state_dict(sd)
+    lens = [200, 140]
+    batch = [(f"s{i}", torch.randint(1, V, (l,)), torch.rand(l, A, 2, nf // 2), ["p"] * l, torch.rand(l, 1, 2, nf // 2),
+              torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l)) for i, l in enumerate(lens)]
+    c = dataset_collate(batch)
+    tokens, targets, lengths = c[1], c[2], c[3]
+    bs, T = tokens.shape
+    shifted = torch.cat([torch.zeros(bs, 1, A, nf), targets[:, 1:].reshape(bs, T - 1, A, nf)], dim=1)
+    kw = dict(src_key_padding_mask=c[8], tgt_key_padding_mask=c[9], src_attn_mask=c[10], tgt_attn_mask=c[11])
+    return model, tokens, targets, lengths, shifted, kw, (V, A, d, heads, L, nf)
+
+
+def gen_transformer_c4(tmod, dataset, p2a_metrics, helpers):
+    """Full-width ArtSpeechTransformer (419.6 M parameters) through the reference: forward as the trainer calls it, the masked
+    Euclidean loss of train_phoneme_to_articulation_transformer.py:113-118, backward.  Weights / inputs are functions of the
+    seeded generator (the test re-runs c4_case); the fixture holds their checksums, the loss, contour slices, and norm, max
+    and a strided slice of every parameter gradient.  eval() mode: the encoder's library-default dropout 0.1 off."""
+    import types as _t
+    model, tokens, targets, lengths, shifted, kw, cfg = c4_case(tmod.ArtSpeechTransformer, dataset.pad_sequence_transformer_collate_fn)
+
+    def loop_forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                     memory_key_padding_mask=None, **_):
+        out = tgt
+        for mod in self.layers:
+            out = mod(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                      tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask)
+        return out
+    model.decoder.forward = _t.MethodType(loop_forward, model.decoder)   # torch 2.0.1's decoder loop (see gen_transformer)
+    model.eval()
+    out = model(tokens, shifted, **kw)
+    loss = masked_mean_loss(p2a_metrics.EuclideanDistance("none"), helpers.make_padding_mask, out, targets, lengths)
+    loss.backward()
+    pos = [(0, 0), (0, 199), (0, 77), (1, 0), (1, 139), (1, 140), (1, 199)]
+    arrays = dict(
+        cfg=np.array(cfg, dtype=np.int64), lengths=lengths.numpy(), positions=np.array(pos),
+        tok_sum=np.int64(tokens.sum().item()), tgt_sum=np.float64(targets.double().sum().item()),
+        w_abs_sum=np.float64(sum(p.detach().double().abs().sum().item() for p in model.parameters())),
+        loss=np.float64(loss.item()), out_sum=np.float64(out.detach().double().sum().item()),
+        out_slices=np.stack([out[b, t].detach().numpy() for b, t in pos]),
+    )
+    # ~10 000 parameter tensors: one row each in packed arrays (an .npz member per tensor would cost 20 MB of zip headers)
+    names, gnorm, gmax, gslice = [], [], [], np.zeros((len(list(model.parameters())), C4_SLICE), np.float32)
+    for i, (k, p) in enumerate(model.named_parameters()):
+        g = p.grad
+        names.append(k)
+        gnorm.append(g.double().norm().item())
+        gmax.append(g.abs().max().item())
+        sl = g.reshape(-1)[:: max(1, g.numel() // C4_SLICE)][:C4_SLICE].numpy()
+        gslice[i, :sl.size] = sl
+    arrays.update(names=np.array("\n".join(names)), gnorm=np.array(gnorm), gmax=np.array(gmax), gslice=gslice)
+    save("transformer_c4_full", **arrays)
+    return dict(loss=float(loss.item()), out_sum=float(out.detach().double().sum()), params=sum(p.numel() for p in model.parameters()))
+
+
 def main():
     only = set(sys.argv[1:])  # e.g. `make_golden.py test_loops`: regenerate just that fixture
     install_shims()
@@ -570,6 +675,28 @@ def main():
     _shim("phoneme_to_articulation.tail_clipper", TailClipper=None)
     dataset = _load("ref_ed_dataset", "phoneme_to_articulation/encoder_decoder/dataset.py")
 
+    if only == {"c2_full"}:
+        res = gen_artspeech_c2(models, p2a_metrics, helpers)
+        path = os.path.join(OUT, "checksums.json")
+        with open(path) as f:
+            allc = json.load(f)
+        allc["cases"]["artspeech_c2_full"] = res
+        with open(path, "w") as f:
+            json.dump(allc, f, indent=1)
+        print(json.dumps(res, indent=1))
+        return
+    if only == {"c4_full"}:
+        sys.modules["phoneme_to_articulation.encoder_decoder.models"] = models
+        tmod = _load("ref_transformer_models", "phoneme_to_articulation/transformer/models.py")
+        res = gen_transformer_c4(tmod, dataset, p2a_metrics, helpers)
+        path = os.path.join(OUT, "checksums.json")
+        with open(path) as f:
+            allc = json.load(f)
+        allc["cases"]["transformer_c4_full"] = res
+        with open(path, "w") as f:
+            json.dump(allc, f, indent=1)
+        print(json.dumps(res, indent=1))
+        return
     if only == {"test_loops"}:
         ref_eval, ref_train = load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_metrics, root_metrics, helpers)
         res = gen_test_loops(models, dataset, p2a_metrics, ed_metrics, settings, ref_eval, ref_train)
@@ -604,6 +731,7 @@ def main():
     sys.modules["phoneme_to_articulation.encoder_decoder.models"] = models  # transformer/models.py:6 imports it by this name
     tmod = _load("ref_transformer_models", "phoneme_to_articulation/transformer/models.py")
     checks["transformer_small"] = gen_transformer(tmod, dataset)
+    checks["transformer_c4_full"] = gen_transformer_c4(tmod, dataset, p2a_metrics, helpers)
     ds2 = _load("ref_deepspeech2", "phoneme_recognition/deepspeech2.py")  # file-path import: the package __init__ needs funcy/seaborn
     checks.update(gen_deepspeech2(ds2))
     # the genuine RNNType enum: execute the reference package __init__ under another name (its absent imports are shimmed)
@@ -626,6 +754,7 @@ def main():
     pc_losses = _load("phoneme_to_articulation.principal_components.losses", "phoneme_to_articulation/principal_components/losses.py")
     checks.update(gen_pc_autoencoder(ae, pc_losses))
     ref_eval, ref_train = load_reference_harnesses(pkg, settings, models, dataset, p2a_metrics, ed_metrics, root_metrics, helpers)
+    checks["artspeech_c2_full"] = gen_artspeech_c2(models, p2a_metrics, helpers)
     checks["test_loops"] = gen_test_loops(models, dataset, p2a_metrics, ed_metrics, settings, ref_eval, ref_train)
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
         json.dump({"torch": torch.__version__, "numpy": np.__version__, "cases": checks}, f, indent=1)

@@ -467,3 +467,52 @@ def test_run_transformer_test_harness(dev, tmp_path):
     assert set(res["tongue"]) == {"x_corr", "y_corr", "p2cp", "p2cp_mm", "med", "med_mm"}
     import os
     assert sum(f == "tract_variables.csv" for _, _, fs in os.walk(tmp_path) for f in fs) == 6
+
+
+def test_full_width_model_matches_reference_fixture(dev):
+    """BASELINE configs[3]'s MODEL at full width (d=256, 6 layers, A=11, 419.6 M parameters) against the reference itself
+    on a two-utterance ragged batch of T=200 (tests/golden/make_golden.py gen_transformer_c4): the seeded recipe
+    (c4_case, one text for both sides) is re-run with this package's classes, checksums in the fixture prove that
+    weights and inputs are the reference run's, then loss, contour slices and norm + strided slice of every one of the
+    ~10 000 parameter gradients are compared."""
+    import importlib.util
+    import os
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)     # definitions only: nothing of /root/reference is touched until its main() runs
+    g = load_golden("transformer_c4_full")
+    model, tokens, targets, lengths, shifted, kw, cfg = mg.c4_case(ArtSpeechTransformer, pad_sequence_transformer_collate_fn)
+    assert tuple(int(v) for v in g["cfg"]) == cfg and np.array_equal(lengths.numpy(), g["lengths"])
+    assert int(tokens.sum()) == int(g["tok_sum"])
+    assert abs(targets.double().sum().item() - float(g["tgt_sum"])) < 1e-6
+    w_abs = sum(p.detach().double().abs().sum().item() for k, p in model.state_dict().items() if k != "positional_encoding.pe"
+                and not k.endswith(".pe"))
+    assert abs(w_abs - float(g["w_abs_sum"])) < 1e-7 * float(g["w_abs_sum"]), (w_abs, float(g["w_abs_sum"]))
+    model = model.to(dev).eval()
+    out = model(tokens.to(dev), shifted.to(dev), **{k: v.to(dev) for k, v in kw.items()})
+    loss = masked_euclidean_loss(out, targets.to(dev), lengths)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6, (loss.item(), float(g["loss"]))
+    for (b, t), want in zip(g["positions"], g["out_slices"]):
+        got = out[int(b), int(t)].detach().cpu().numpy()
+        assert (np.abs(got - want) <= 1e-4 * np.abs(want) + 2e-6).all(), (b, t, np.abs(got - want).max())
+    loss.backward()
+    gv = model.named_grad_views()
+    names = str(g["names"]).split("\n")
+    assert set(names) == set(gv), set(names) ^ set(gv)
+    n = g["gslice"].shape[1]
+    worst_norm, worst_slice = ("", 0.0), ("", 0.0)
+    for i, k in enumerate(names):
+        v = gv[k]
+        gn, gm = float(g["gnorm"][i]), float(g["gmax"][i])
+        e = abs(float(v.double().norm()) - gn) / max(gn, 1e-30)
+        worst_norm = max(worst_norm, (k, e), key=lambda t_: t_[1])
+        sl = v.reshape(-1)[:: max(1, v.numel() // n)][:n].cpu().numpy()
+        es = float(np.abs(sl - g["gslice"][i, :sl.size]).max()) / max(gm, 1e-30)
+        worst_slice = max(worst_slice, (k, es), key=lambda t_: t_[1])
+    print("full-width transformer: worst gradient norm error", worst_norm, " worst slice error / max|g|", worst_slice)
+    # the wide tolerance of the full-size BiGRU fixture for the same reason (ReLU decisions within an ulp of zero)
+    assert worst_norm[1] < 5e-4, worst_norm
+    assert worst_slice[1] < 5e-3, worst_slice
