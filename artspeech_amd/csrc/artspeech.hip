@@ -37,7 +37,7 @@ struct Carve {
 
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
-    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, bits1, bits2, total;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, slab3, bits1, bits2, total;
 };
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
@@ -67,6 +67,7 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.dw3f = c.take(A * O * D);
     w.slab = c.take(SLAB_FLOATS);   // split-K partial tiles of the weight-gradient GEMMs (main stream)
     w.slab2 = c.take(SLAB_FLOATS);  // same, for GEMMs issued on the side stream
+    w.slab3 = c.take(SLAB_FLOATS);  // same, second side stream
     w.bits1 = c.take(rows * A * (D / 64) * 2);  // ReLU masks of r1 / r2: one bit per element (64-bit words, 16-byte aligned)
     w.bits2 = c.take(rows * A * (D / 64) * 2);
     w.total = c.off;
@@ -308,11 +309,14 @@ int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t ro
 struct StreamState {
     int dev = -1;
     hipStream_t owner = nullptr;
-    hipStream_t side = nullptr;                                   // created on first use with overlap on
+    hipStream_t side = nullptr, side2 = nullptr;                  // created on first use with overlap on
     hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
+    hipEvent_t fork2[3] = {nullptr, nullptr, nullptr}, join2 = nullptr;   // second side stream
     hipEvent_t heads = nullptr;                                   // recorded by as_artspeech_bwd
 };
 int g_overlap = -1;  // -1: not decided yet (environment), 0: off, 1: on
+// AS_ONE_SIDE_STREAM (ablation): the hidden-to-hidden weight gradients queue on the first side stream (round-2 start)
+const bool g_one_side = getenv("AS_ONE_SIDE_STREAM") != nullptr;
 std::mutex g_state_mu;
 std::vector<StreamState*> g_states;
 
@@ -331,7 +335,9 @@ StreamState* state_for(hipStream_t st) {
     p->owner = st;
     bool ok = hipEventCreateWithFlags(&p->heads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->join2, hipEventDisableTiming) == hipSuccess;
     for (auto& e : p->fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : p->fork2) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         delete p;
         return nullptr;
@@ -353,6 +359,8 @@ StreamState* side_for(hipStream_t st) {
             p->side = nullptr;
             return nullptr;
         }
+        // optional: without it, its work goes to `side`
+        if (!g_one_side && !p->side2 && hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking) != hipSuccess) p->side2 = nullptr;
     }
     return p;
 }
@@ -554,6 +562,10 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     StreamState* sd = side_for(st);
     hipStream_t s2 = sd ? sd->side : st;      // no side stream: everything in order on `st`
     float* sl2 = sd ? slab2 : slab;
+    // second side stream: the small hidden-to-hidden weight gradients (few workgroups, latency bound), so that they run
+    // beside the head / input-projection ones instead of queueing behind them: -9 us per step
+    hipStream_t s3 = (sd && sd->side2) ? sd->side2 : s2;
+    float* sl3 = (sd && sd->side2) ? ws + w.head + hw.slab3 : sl2;
     AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
@@ -567,14 +579,15 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
+    if (s3 != s2) AS_TRY(fork_to(st, s3, sd->fork2[1]));
     AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
     AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
     // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame; both directions as one batch of two
-    AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh1, 6 * H, ws + w.y1, 2 * H, G + L.w_hh[1], H, 3 * H, H, R, s2, sl2, G + L.b_hh[1], 3 * H, 2,
+    AS_STEP("grub.dw_hh", s3, gemm_tn(ws + w.dgh1, 6 * H, ws + w.y1, 2 * H, G + L.w_hh[1], H, 3 * H, H, R, s3, sl3, G + L.b_hh[1], 3 * H, 2,
                    3 * H, H, 3L * H * H, -1, T, 2));
     // ---- layer-0 gradients: hidden-to-hidden on the side stream, embedding / input projection here
-    if (sd) AS_TRY(fork_to(st, s2, sd->fork[2]));
-    AS_STEP("grub.dw_hh", s2, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s2, sl2, G + L.b_hh[0], 3 * H, 2,
+    if (sd) AS_TRY(fork_to(st, s3, s3 != s2 ? sd->fork2[2] : sd->fork[2]));
+    AS_STEP("grub.dw_hh", s3, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s3, sl3, G + L.b_hh[0], 3 * H, 2,
                    3 * H, H, 3L * H * H, -1, T, 2));
     // embedding + layer-0 input projection through the token table
     AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
@@ -585,6 +598,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
         AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st, 1, 0, 0, 0, slab));
     }
-    if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side stream's work
+    if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side streams' work
+    if (s3 != s2) AS_TRY(fork_to(s3, st, sd->join2));
     return 0;
 }

@@ -629,7 +629,8 @@ def test_full_size_matches_reference_fixture(dev):
         # tolerance scaled by the whole tensor's max (from the fixture).  Wider than the small fixtures' 1e-5: of the 18 M
         # ReLU decisions per head layer at this size a handful sit within an ulp of zero and differ between any two fp32
         # evaluation orders, each moving a gradient element by one full frame term (tests/test_oracle_golden.py measures
-        # up to 2.5e-3 of max|g| between the reference and the oracle)
+        # up to 2.5e-3 of max|g| between the reference and the fp64 oracle; this path: 1.5e-3 on embedding.weight, where the
+        # oracle shows 1.3e-3 too, <= 1e-4 elsewhere)
         assert_grad_close(sl, g["gslice." + k], f"c2 full: {k}", atol_abs=5e-3 * float(g["gmax." + k]))
 
 
