@@ -580,25 +580,53 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
     if (s3 != s2) AS_TRY(fork_to(st, s3, sd->fork2[1]));
-    AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
+    // layer 0 sits under the token table: the recurrence keeps per-token sums of its input-side gate gradients in LDS and
+    // leaves B tables [V][6H] where dgi0 would have gone (V <= T: they fit), so there is no dgi0 and no segmented-sum
+    // pass; else dgi0 + as_token_segsum below
+    int tok_sums = 0;
+    if (V <= T) {
+        AS_PROF("gru.bwd_l0", st);
+        tok_sums = as_gru_bidir_bwd_tokens(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgh0, tokens,
+                                           tok_stride, V, ws + w.dgi0, st);
+        AS_REQUIRE(tok_sums >= 0, tok_sums, "gru.bwd_l0: launch failed");
+    }
+    if (!tok_sums)
+        AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
     AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
     // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame; both directions as one batch of two
     AS_STEP("grub.dw_hh", s3, gemm_tn(ws + w.dgh1, 6 * H, ws + w.y1, 2 * H, G + L.w_hh[1], H, 3 * H, H, R, s3, sl3, G + L.b_hh[1], 3 * H, 2,
                    3 * H, H, 3L * H * H, -1, T, 2));
-    // ---- layer-0 gradients: hidden-to-hidden on the side stream, embedding / input projection here
+    // ---- layer-0 gradients.  What follows the last recurrence is the step's tail, and a cross-stream wait costs ~10 us
+    // each way on top of the work it guards (measured on the timeline): the LONGER of the two remaining jobs therefore
+    // stays on the caller's stream, back to back with the recurrence, and the shorter one forks off.
+    //   token sums in the recurrence: hidden-to-hidden GEMM (~30 us) here, table reduction + embedding grads (~13 us) aside;
+    //   otherwise: segmented sum + embedding grads (~40 us) here, the GEMM aside.
+    hipStream_t s_hh = tok_sums ? st : s3, s_emb = tok_sums ? s3 : st;
+    float* sl_hh = tok_sums ? slab : sl3;
     if (sd) AS_TRY(fork_to(st, s3, s3 != s2 ? sd->fork2[2] : sd->fork[2]));
-    AS_STEP("grub.dw_hh", s3, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s3, sl3, G + L.b_hh[0], 3 * H, 2,
+    AS_STEP("grub.dw_hh", s_hh, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s_hh, sl_hh, G + L.b_hh[0], 3 * H, 2,
                    3 * H, H, 3L * H * H, -1, T, 2));
     // embedding + layer-0 input projection through the token table
-    AS_STEP("grub.segsum", st, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, st, slab, SLAB_FLOATS));
+    if (tok_sums)
+        AS_STEP("grub.segsum", s_emb, as_sum_partials(ws + w.dgi0, (long)V * 6 * H, B, ws + w.dtab0, s_emb));
+    else
+        AS_STEP("grub.segsum", s_emb, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, s_emb, slab, SLAB_FLOATS));
     if (E <= 256 && V <= 128) {  // embedding + input-projection gradients of layer 0 from the token sums: one small launch
-        AS_STEP("grub.dw_ih0", st, as_emb_grads(ws + w.dtab0, P + L.embedding, P + L.w_ih[0], V, 6 * H, E, G + L.w_ih[0], G + L.b_ih[0],
-                                                G + L.embedding, st));
+        AS_STEP("grub.dw_ih0", s_emb, as_emb_grads(ws + w.dtab0, P + L.embedding, P + L.w_ih[0], V, 6 * H, E, G + L.w_ih[0], G + L.b_ih[0],
+                                                G + L.embedding, s_emb));
     } else {
-        AS_STEP("grub.dw_ih0", st, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, st, slab, G + L.b_ih[0], 0));
-        AS_STEP("grub.demb", st, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, st, 1, 0, 0, 0, slab));
+        // (only reached with s_emb == st or with the main slab free: token sums need V <= T, these need V > 128)
+        float* sl_e = tok_sums ? sl3 : slab;
+        AS_STEP("grub.dw_ih0", s_emb, gemm_tn(ws + w.dtab0, 6 * H, P + L.embedding, E, G + L.w_ih[0], E, 6 * H, E, V, s_emb, sl_e, G + L.b_ih[0], 0));
+        AS_STEP("grub.demb", s_emb, gemm_nn(ws + w.dtab0, 6 * H, P + L.w_ih[0], E, G + L.embedding, E, V, E, 6 * H, s_emb, 1, 0, 0, 0, sl_e));
     }
-    if (sd) AS_TRY(fork_to(s2, st, sd->join));  // join: `st` continues only after the side streams' work
-    if (s3 != s2) AS_TRY(fork_to(s3, st, sd->join2));
+    // join: `st` continues only after the side streams' work.  One wait on `st` (each costs the tail a few microseconds):
+    // the second side stream first waits for the first one, then `st` waits for it alone.
+    if (sd && s3 != s2) {
+        AS_TRY(fork_to(s2, s3, sd->join));
+        AS_TRY(fork_to(s3, st, sd->join2));
+    } else if (sd) {
+        AS_TRY(fork_to(s2, st, sd->join));
+    }
     return 0;
 }

@@ -23,3 +23,10 @@ struct as_lin {
     const float* xhat; long ldx, x_batch; const float* rstd_in; const unsigned long long* bits_in;
 };
 int as_lin_try(const as_lin* a, hipStream_t st);
+
+// gru.hip: backward recurrence of layer 0 under a token table; see the kernel.  1 = launched, 0 = not a case, < 0 = error.
+int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
+                            int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,
+                            float* part, hipStream_t st);
+// rowops.hip: out[i] = sum over chunks (fixed order) of part[chunk][i], i < n
+int as_sum_partials(const float* part, long n, int chunks, float* out, hipStream_t st);

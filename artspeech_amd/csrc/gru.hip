@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "as_common.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -278,12 +279,21 @@ __global__ __launch_bounds__(LPU * H) void gru_bwd_kernel(const float* __restric
 // 1/16 of the gate rows (the same 96 weight VGPRs), reads only 3H/16 gate gradients per step (6 ds_read_b128 at H = 128)
 // and the four partial sums are all-reduced across the row with 4 DPP steps each (quad xor 1, xor 2, half-row mirror,
 // row mirror).  Lane r of a row then plays the old role for unit 4*row + (r & 3), plane r >> 2.
-template <int H>
+// TOK (layer 0 under a token table): the input-side gate gradients are only ever summed per token (the embedding and the
+// input projection see them through the table, rowops.hip emb_grads_kernel), so instead of writing dgi [B][T][2][3H] for a
+// later segmented-sum pass, every workgroup keeps the sums of ITS utterance and direction in an LDS table [V][3H] (one
+// read-modify-write per lane and step, off the recurrence's dependency chain; each word has one owner lane, so the order
+// of additions is the frame order: reproducible) and stores it once at the end into part [B][V][2 * 3H]; dgi is not
+// touched.  A fixed-order reduction over the B tables follows (token_segsum_reduce_kernel).
+template <int H, bool TOK>
 __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ gates, const float* __restrict__ w_hh,
                                                             const int* __restrict__ lengths, int T, float* __restrict__ dgi,
-                                                            float* __restrict__ dgh, unsigned long long* __restrict__ dbg) {
+                                                            float* __restrict__ dgh, unsigned long long* __restrict__ dbg,
+                                                            const int64_t* __restrict__ tokens, long tok_stride, int V,
+                                                            float* __restrict__ part) {
     constexpr int NT = 4 * H;
+    extern __shared__ float tab[];            // TOK: [V][3H] + a dummy word per lane + T token offsets
     constexpr int VL = 3 * H / 16;            // gate rows per lane
     // diagnostic (as_gru_debug_stamps): shader-clock and 100 MHz wall-clock stamps around the recurrence of this workgroup;
     // dbg is null in every product launch and no stamp executes then
@@ -320,10 +330,25 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += NT) {  // padded frames feed the time-batched GEMMs as zeros
         const long t = i / (3 * H), c = i % (3 * H);
         const long o = (((long)b * T + t) * 2 + dir) * 3 * H + c;
-        dgi[o] = 0.f;
+        if constexpr (!TOK) dgi[o] = 0.f;
         dgh[o] = 0.f;
     }
-    if (len <= 0) return;
+    float* part_wg = nullptr;
+    if constexpr (TOK) {
+        for (int i = tid; i < V * 3 * H; i += NT) tab[i] = 0.f;
+        // the utterance's tokens as table offsets, staged once: a per-step global (or scalar) load of the token put a
+        // memory round trip on the step (+0.3 us, measured); an LDS broadcast read one step ahead costs nothing
+        int* toff = reinterpret_cast<int*>(tab + (long)V * 3 * H + NT);
+        for (int t = tid; t < len; t += NT) toff[t] = (int)tokens[(long)b * tok_stride + t] * (3 * H);
+        part_wg = part + (long)b * V * 6 * H + (long)dir * 3 * H;   // + v * 6H + column
+        if (len <= 0) {
+            for (int i = tid; i < V * 3 * H; i += NT) part_wg[(long)(i / (3 * H)) * 6 * H + i % (3 * H)] = 0.f;
+            return;
+        }
+        // the table is first touched after the first barrier of the loop below
+    } else {
+        if (len <= 0) return;
+    }
 
     const int t0 = dir ? 0 : len - 1;  // opposite to the forward walk
     const int dt = dir ? 1 : -1;
@@ -334,13 +359,13 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
     float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
     const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl >= 2 ? -1 : 0;
-    struct In { float r, z, n, hn, hprev, dyv; };
+    struct In { float r, z, n, hn, hprev, dyv; bool has_prev; };
     auto load = [&](long fr, bool has_prev) {
         In v;
         const float* gp = gtb + fr * 8 * H;
         v.r = gp[0]; v.z = gp[H]; v.n = gp[2 * H]; v.hn = gp[3 * H];
-        const float hp = yb[(fr + (has_prev ? dt : 0)) * 2 * H];
-        v.hprev = has_prev ? hp : 0.f;
+        v.hprev = yb[(fr + (has_prev ? dt : 0)) * 2 * H];
+        v.has_prev = has_prev;
         v.dyv = dyb[fr * 2 * H];
         return v;
     };
@@ -354,14 +379,23 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     long fr = (long)b * T + t0;
     float dh = 0.f;
     In cur_in = load(fr, len > 1);
+    const int tmask = pl < 3 ? -1 : 0;                                                      // dummy word: same for every token
+    float* tabk = pl < 3 ? tab + sel * H + k : tab + (long)V * 3 * H + tid;                 // + (token offset & tmask)
+    const int* toff = reinterpret_cast<const int*>(tab + (long)V * 3 * H + NT);
+    int toff_cur = 0;
+    if constexpr (TOK) {
+        __syncthreads();   // offsets staged, table zeroed
+        toff_cur = toff[t0];
+    }
     for (int s = 0; s < len; ++s) {
         const int cur = s & 1;
         const int adv = s + 1 < len ? dt : 0;
         const In nxt = load(fr + adv, s + 2 < len);
+
         const float rg = cur_in.r, z = cur_in.z, n = cur_in.n, hn = cur_in.hn;
         const float dht = dh + cur_in.dyv;
         const float dn = dht * (1.f - z);
-        const float dz = dht * (cur_in.hprev - n);
+        const float dz = dht * ((cur_in.has_prev ? cur_in.hprev : 0.f) - n);
         const float dnt = dn * (1.f - n * n);
         const float g_r = dnt * hn * rg * (1.f - rg);
         const float g_z = dz * z * (1.f - z);
@@ -370,15 +404,27 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
         const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
         gbuf[cur][sel * H + k] = vh;
-        dgib[fr * 6 * H] = vi;
+        if constexpr (!TOK) dgib[fr * 6 * H] = vi;
         dghb[fr * 6 * H] = vh;
         __syncthreads();
+
         f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         if constexpr (VW == 4) {
             const float4* gq = reinterpret_cast<const float4*>(gbuf[cur]);
             float4 gv[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) gv[c] = gq[c * 16 + r];
+            // TOK: the table word of this step's token is read BEHIND the gate reads (LDS answers in order) and written
+            // back after the FMAs below: its round trip hides under them instead of standing before them.  The fourth lane
+            // of a unit (a duplicate of the n plane) works on a private dummy word, so no lane is masked off.
+            float* tw = nullptr;
+            float told = 0.f;
+            int toff_nxt = 0;
+            if constexpr (TOK) {
+                tw = tabk + (toff_cur & tmask);
+                told = *tw;
+                toff_nxt = toff[t0 + (s + 1 < len ? s + 1 : s) * dt];   // broadcast read, used one step later
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -388,6 +434,11 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
                     a[kk] = __builtin_elementwise_fma(wt[kk][2 * c], lo, a[kk]);
                     a[kk] = __builtin_elementwise_fma(wt[kk][2 * c + 1], hi, a[kk]);
                 }
+            }
+            if constexpr (TOK) {
+                __builtin_amdgcn_sched_barrier(0);
+                *tw = told + vi;
+                toff_cur = toff_nxt;
             }
         } else {
             const float2* gq = reinterpret_cast<const float2*>(gbuf[cur]);
@@ -401,6 +452,10 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_elementwise_fma(wt[kk][c], g2, a[kk]);
             }
+            if constexpr (TOK) {
+                tabk[toff_cur & tmask] += vi;
+                toff_cur = toff[t0 + (s + 1 < len ? s + 1 : s) * dt];
+            }
         }
         float acc = a[0].x + a[0].y;
         acc = dpp_add(acc, a[3].x + a[3].y, std::integral_constant<int, 0x39>{});   // quad_perm [1,2,3,0]
@@ -412,6 +467,10 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         cur_in = nxt;
         fr += dt;
         // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    }
+    if constexpr (TOK) {
+        __syncthreads();
+        for (int i = tid; i < V * 3 * H; i += NT) part_wg[(long)(i / (3 * H)) * 6 * H + i % (3 * H)] = tab[i];
     }
     if (dbg != nullptr && threadIdx.x == 0) {
         unsigned long long* d = dbg + 4L * (blockIdx.y * gridDim.x + blockIdx.x);
@@ -431,6 +490,7 @@ constexpr int lpu_of(int) { return 4; }
 }  // namespace
 
 static unsigned long long* g_gru_dbg = nullptr;
+constexpr int AS_GRU_TOK_LDS_MAX = 128 * 1024;   // token-sum table of the layer-0 backward recurrence (one workgroup per CU)
 extern "C" void as_gru_debug_stamps(uint64_t* buf) { g_gru_dbg = (unsigned long long*)buf; }
 
 static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
@@ -474,20 +534,29 @@ extern "C" int as_gru_unidir_fwd(const float* gi, const float* w_hh, const float
     return gru_fwd_launch(gi, nullptr, 0, w_hh, b_hh, lengths, B, T, H, y, nullptr, 1, stream);
 }
 
-extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const float* w_hh,
-                                const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* dgi, float* dgh,
-                                void* stream) {
-    AS_REQUIRE(dy && y && gates && w_hh && lengths && dgi && dgh, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: null pointer");
+static int gru_bwd_launch(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
+                          int32_t B, int32_t T, int32_t H, float* dgi, float* dgh, const int64_t* tokens, int64_t tok_stride,
+                          int32_t V, float* part, void* stream) {
+    AS_REQUIRE(dy && y && gates && w_hh && lengths && (dgi || tokens) && dgh, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: null pointer");
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: B=%d T=%d", B, T);
+    AS_REQUIRE(!tokens || (part && V > 0 && tok_stride >= T), AS_ERR_BAD_ARG, "as_gru_bidir_bwd: token table arguments");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
     static const bool unit_layout = getenv("AS_GRU_BWD_UNIT") != nullptr;  // ablation: the 4-lanes-per-unit layout
+    const size_t shm = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
 #define AS_GRU_BWD(HH)                                                                                                        \
-    if (unit_layout)                                                                                                          \
+    if (tokens) {                                                                                                             \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_row_kernel<HH, true>),       \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, AS_GRU_TOK_LDS_MAX);   \
+        AS_REQUIRE(attr == hipSuccess, (int)attr, "as_gru_bidir_bwd: cannot reserve LDS: %s", hipGetErrorString(attr));       \
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, true>), grid, dim3(4 * HH), shm, st, dy, y, gates, w_hh, lengths, T, dgi,  \
+                           dgh, g_gru_dbg, tokens, (long)tok_stride, V, part);                                                 \
+    } else if (unit_layout)                                                                                                   \
         hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
                            T, dgi, dgh);                                                                                      \
     else                                                                                                                      \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi, dgh, g_gru_dbg)
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, false>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi,   \
+                           dgh, g_gru_dbg, nullptr, 0L, 0, nullptr)
     switch (H) {
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
@@ -499,4 +568,23 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
 #undef AS_GRU_BWD
     AS_LAUNCH_CHECK("as_gru_bidir_bwd");
     return 0;
+}
+
+extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const float* w_hh,
+                                const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* dgi, float* dgh,
+                                void* stream) {
+    AS_REQUIRE(dgi, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: null pointer");
+    return gru_bwd_launch(dy, y, gates, w_hh, lengths, B, T, H, dgi, dgh, nullptr, 0, 0, nullptr, stream);
+}
+
+// Layer 0 under a token table (internal, gemm_internal.h): per-utterance token sums of the input-side gate gradients,
+// part [B][V][6H], instead of dgi.  0 = not a case for it (V * 3H floats must fit the LDS budget): the caller takes
+// as_gru_bidir_bwd + as_token_segsum.
+int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
+                            int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,
+                            float* part, hipStream_t st) {
+    static const bool off = getenv("AS_NO_GRU_TOKSUM") != nullptr;   // ablation: dgi + the segmented-sum kernel
+    if (off || !tokens || ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) > AS_GRU_TOK_LDS_MAX) return 0;
+    const int rc = gru_bwd_launch(dy, y, gates, w_hh, lengths, B, T, H, nullptr, dgh, tokens, tok_stride, V, part, st);
+    return rc == 0 ? 1 : rc;
 }

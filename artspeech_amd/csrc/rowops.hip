@@ -711,6 +711,11 @@ int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int 
     AS_LAUNCH_CHECK("token_segsum");
     return 0;
 }
+int as_sum_partials(const float* part, long n, int chunks, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(token_segsum_reduce_kernel, dim3(as_cdiv(n, 256)), dim3(256), 0, st, part, n, chunks, out);
+    AS_LAUNCH_CHECK("sum_partials");
+    return 0;
+}
 int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int C, int E, float* dW, float* db, float* demb,
                  hipStream_t st) {
     AS_REQUIRE(C % 16 == 0 && E <= 256 && V <= 128, AS_ERR_UNSUPPORTED, "emb_grads: V=%d C=%d E=%d", V, C, E);
