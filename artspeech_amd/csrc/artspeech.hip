@@ -583,15 +583,15 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // layer 0 sits under the token table: the recurrence keeps per-token sums of its input-side gate gradients in LDS and
     // leaves B tables [V][6H] where dgi0 would have gone (V <= T: they fit), so there is no dgi0 and no segmented-sum
     // pass; else dgi0 + as_token_segsum below
-    int tok_sums = 0;
-    if (V <= T) {
+    const int tok_sums = V <= T && as_gru_bwd_tokens_fits(V, H, T);
+    if (tok_sums) {
         AS_PROF("gru.bwd_l0", st);
-        tok_sums = as_gru_bidir_bwd_tokens(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgh0, tokens,
-                                           tok_stride, V, ws + w.dgi0, st);
-        AS_REQUIRE(tok_sums >= 0, tok_sums, "gru.bwd_l0: launch failed");
-    }
-    if (!tok_sums)
+        const int rc = as_gru_bidir_bwd_tokens(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgh0, tokens,
+                                               tok_stride, V, ws + w.dgi0, st);
+        AS_REQUIRE(rc == 1, rc < 0 ? rc : AS_ERR_UNSUPPORTED, "gru.bwd_l0: launch failed");
+    } else {
         AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
+    }
     AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
     // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame; both directions as one batch of two
     AS_STEP("grub.dw_hh", s3, gemm_tn(ws + w.dgh1, 6 * H, ws + w.y1, 2 * H, G + L.w_hh[1], H, 3 * H, H, R, s3, sl3, G + L.b_hh[1], 3 * H, 2,

@@ -25,6 +25,7 @@ struct as_lin {
 int as_lin_try(const as_lin* a, hipStream_t st);
 
 // gru.hip: backward recurrence of layer 0 under a token table; see the kernel.  1 = launched, 0 = not a case, < 0 = error.
+bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T);   // the [V][3H] table + T offsets fit the kernel's LDS budget
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,
                             float* part, hipStream_t st);

@@ -580,11 +580,14 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
 // Layer 0 under a token table (internal, gemm_internal.h): per-utterance token sums of the input-side gate gradients,
 // part [B][V][6H], instead of dgi.  0 = not a case for it (V * 3H floats must fit the LDS budget): the caller takes
 // as_gru_bidir_bwd + as_token_segsum.
+bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T) {
+    static const bool off = getenv("AS_NO_GRU_TOKSUM") != nullptr;   // ablation: dgi + the segmented-sum kernel
+    return !off && ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) <= AS_GRU_TOK_LDS_MAX;
+}
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,
                             float* part, hipStream_t st) {
-    static const bool off = getenv("AS_NO_GRU_TOKSUM") != nullptr;   // ablation: dgi + the segmented-sum kernel
-    if (off || !tokens || ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) > AS_GRU_TOK_LDS_MAX) return 0;
+    if (!tokens || !as_gru_bwd_tokens_fits(V, H, T)) return 0;
     const int rc = gru_bwd_launch(dy, y, gates, w_hh, lengths, B, T, H, nullptr, dgh, tokens, tok_stride, V, part, st);
     return rc == 0 ? 1 : rc;
 }

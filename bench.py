@@ -79,12 +79,14 @@ def phase_bytes(rows):
     return {
         # recurrence, both directions: gi rows in, y + 4 gate planes out (forward); dy, y, gates in, dgi + dgh out
         "gru.fwd_l0": rows * 2 * (H + 4 * H) * f4, "gru.fwd_l1": rows * 2 * (3 * H + H + 4 * H) * f4,
-        "gru.bwd_l1": rows * 2 * (H + H + 4 * H + 6 * H) * f4, "gru.bwd_l0": rows * 2 * (H + H + 4 * H + 6 * H) * f4,
+        # layer 0 (token-table variant): no dgi; the per-utterance token sums [B][V][6H] leave the kernel instead
+        "gru.bwd_l1": rows * 2 * (H + H + 4 * H + 6 * H) * f4, "gru.bwd_l0": rows * 2 * (H + H + 4 * H + 3 * H) * f4 + (rows // T) * V * 6 * H * f4,
         "loss": rows * A * 2 * N * 3 * f4,
     }
 
 
-GRU_BWD_KERNEL = "gru_bwd_row_kernel<128>"
+GRU_BWD_KERNEL = "gru_bwd_row_kernel<128, false>"      # layer 1 (rocprofv3's name); layer 0 runs the token-sum variant
+GRU_BWD_TOK_KERNEL = "gru_bwd_row_kernel<128, true>"
 
 
 def pmc_traffic(kernel):
@@ -308,16 +310,18 @@ def main():
         rows = head["per_gpu_batch"] * T
         flops, nbytes = gemm_flops(rows), phase_bytes(rows)
         # (1) the HBM-side entry: the backward recurrence, ONE kernel launched twice per step (layer 1, layer 0)
-        gb = [kernels[k] for k in ("gru.bwd_l0", "gru.bwd_l1") if k in kernels]
+        gb = kernels.get("gru.bwd_l1")
         if gb:
-            per_launch_us = sum(k["us_per_step"] for k in gb) / sum(k["launches_per_step"] for k in gb)
-            per_launch = nbytes["gru.bwd_l1"]
-            ach = per_launch / (per_launch_us * 1e-6) / 1e9
-            roofline = {"kernel": f"{GRU_BWD_KERNEL} (gru.bwd_l0 + gru.bwd_l1)", "bound": "hbm", "achieved": round(ach, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": pmc_traffic(GRU_BWD_KERNEL), "us_per_launch": round(per_launch_us, 2),
-                        "algorithmic_bytes_per_launch": per_launch,
-                        "note": "dependent-step (latency) bound: 200 sequential recurrent steps per launch"}
+            def entry(kernel, phase):
+                us = kernels[phase]["us_per_step"] / kernels[phase]["launches_per_step"]
+                ach = nbytes[phase] / (us * 1e-6) / 1e9
+                return {"kernel": f"{kernel} ({phase})", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel),
+                        "us_per_launch": round(us, 2), "algorithmic_bytes_per_launch": nbytes[phase]}
+            roofline = entry(GRU_BWD_KERNEL, "gru.bwd_l1")
+            roofline["note"] = "dependent-step (latency) bound: 200 sequential recurrent steps per launch"
+            if "gru.bwd_l0" in kernels and kernels["gru.bwd_l0"]["launches_per_step"] == 1:
+                roofline["layer0_variant"] = entry(GRU_BWD_TOK_KERNEL, "gru.bwd_l0")
         else:
             roofline = {}
         # (2) the matrix side: every GEMM phase grouped by the kernel that runs it; FLOPs / time / fp32-MFMA peak.
