@@ -41,7 +41,7 @@ __device__ __forceinline__ float unit_sum(float v) {
     return v;
 }
 
-template <int H, int LPU, bool TRAIN, bool TOK>
+template <int H, int LPU, bool TRAIN, bool TOK, int AHEAD>
 __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
                                                           long tok_stride, const float* __restrict__ w_hh,
                                                           const float* __restrict__ b_hh, const int* __restrict__ lengths,
@@ -86,26 +86,24 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     float* gb = gates + (long)dir * 4 * H + j;       // + frame * nd*4H, planes r, z, n, hn at + plane * H   (TRAIN)
     const float* gib = gi + (long)dir * 3 * H + j;   // + row * nd*3H
     const long ys = (long)nd * H, gs = (long)nd * 4 * H, is = (long)nd * 3 * H;
-    long fr = (long)b * T + t0;                      // frame index of the current step
     // the LPU lanes of a unit hold identical gate values: lane q stores planes q, q + LPU, ... (branch-free selects)
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
 
     float h = 0.f;
-    float gr, gz, gn;
-    {
-        const long row = TOK ? (long)tok_s[t0] : fr;
+    struct Gi { float r, z, n; };
+    // input projection of step u (clamped to the last step: the look-ahead stays inside the sequence)
+    auto load_step = [&](int u) {
+        const int uc = u < len ? u : len - 1;
+        const int tu = t0 + uc * dt;
+        const long row = TOK ? (long)tok_s[tu] : (long)b * T + tu;
         const float* p = gib + row * is;
-        gr = p[0]; gz = p[H]; gn = p[2 * H];
-    }
-    int t = t0;
-    for (int s = 0; s < len; ++s) {
+        return Gi{p[0], p[H], p[2 * H]};
+    };
+    // One recurrent step: consumes `ci` (loaded AHEAD steps ago) and starts the loads of step s + AHEAD into `fill`.
+    auto step = [&](int s, const Gi& ci, Gi& fill) {
         const int cur = s & 1;
-        // next step's input projection (independent of the recurrence): in flight during this step.
-        // On the last step the look-ahead re-reads the current row (stays inside the sequence).
-        const int adv = s + 1 < len ? dt : 0;
-        const long rown = TOK ? (long)tok_s[t + adv] : fr + adv;
-        const float* pn = gib + rown * is;
-        const float ngr = pn[0], ngz = pn[H], ngn = pn[2 * H];
+        const long fr = (long)b * T + t0 + (long)s * dt;   // frame of this step
+        fill = load_step(s + AHEAD);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
         f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
 #pragma unroll
@@ -129,10 +127,10 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
                 }
         }
         const float sr = unit_sum<LPU>(ar.x + ar.y), sz = unit_sum<LPU>(az.x + az.y), sn = unit_sum<LPU>(an.x + an.y);
-        const float r = as_sigmoid(gr + (sr + bh_r));
-        const float z = as_sigmoid(gz + (sz + bh_z));
+        const float r = as_sigmoid(ci.r + (sr + bh_r));
+        const float z = as_sigmoid(ci.z + (sz + bh_z));
         const float hn = sn + bh_n;
-        const float n = as_tanh(gn + r * hn);
+        const float n = as_tanh(ci.n + r * hn);
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
         // the lanes of a unit hold identical values: all of them store (same word) -> no divergence
@@ -150,10 +148,27 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
                 gb[fr * gs + (2 + q) * H] = __int_as_float(gc);
             }
         }
-        gr = ngr; gz = ngz; gn = ngn;
-        fr += dt;
-        t += dt;
         __syncthreads();
+    };
+    if constexpr (AHEAD == 1) {
+        Gi a = load_step(0), bn;
+        for (int s = 0; s < len; ++s) {
+            step(s, a, bn);
+            a = bn;
+        }
+    } else {
+        // Two steps of look-ahead: three operand sets whose roles rotate by NAME through a loop unrolled by three.  A
+        // register-to-register rotation is a CONSUMER of the newest loads: the wave would wait for them at the end of the
+        // step that issued them, and the memory round trip (not the arithmetic) would set the step time.
+        Gi a = load_step(0), bq = load_step(1), c;
+        int s = 0;
+        for (; s + 2 < len; s += 3) {
+            step(s, a, c);
+            step(s + 1, bq, a);
+            step(s + 2, c, bq);
+        }
+        if (s < len) step(s, a, c);
+        if (s + 1 < len) step(s + 1, bq, a);
     }
 }
 
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(LPU * H) void gru_bwd_kernel(const float* __restric
 // read-modify-write per lane and step, off the recurrence's dependency chain; each word has one owner lane, so the order
 // of additions is the frame order: reproducible) and stores it once at the end into part [B][V][2 * 3H]; dgi is not
 // touched.  A fixed-order reduction over the B tables follows (token_segsum_reduce_kernel).
-template <int H, bool TOK>
+template <int H, bool TOK, int AHEAD>
 __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ gates, const float* __restrict__ w_hh,
                                                             const int* __restrict__ lengths, int T, float* __restrict__ dgi,
@@ -376,9 +391,8 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     auto dpp_add = [](float acc, float v, auto ctrl) {
         return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, true));
     };
-    long fr = (long)b * T + t0;
+    const long fbase = (long)b * T + t0;   // frame of step u: fbase + u * dt
     float dh = 0.f;
-    In cur_in = load(fr, len > 1);
     const int tmask = pl < 3 ? -1 : 0;                                                      // dummy word: same for every token
     float* tabk = pl < 3 ? tab + sel * H + k : tab + (long)V * 3 * H + tid;                 // + (token offset & tmask)
     const int* toff = reinterpret_cast<const int*>(tab + (long)V * 3 * H + NT);
@@ -387,15 +401,22 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         __syncthreads();   // offsets staged, table zeroed
         toff_cur = toff[t0];
     }
-    for (int s = 0; s < len; ++s) {
+    // Operands of step u (clamped to the last step: the look-ahead stays inside the sequence); h_prev exists for all but
+    // the last step of the backward walk.
+    auto load_step = [&](int u) {
+        const int uc = u < len ? u : len - 1;
+        return load(fbase + (long)uc * dt, uc + 1 < len);
+    };
+    // One recurrent step: consumes `ci` (loaded AHEAD steps ago), starts the loads of step s + AHEAD into `fill`.
+    auto step = [&](int s, const In& ci, In& fill) {
         const int cur = s & 1;
-        const int adv = s + 1 < len ? dt : 0;
-        const In nxt = load(fr + adv, s + 2 < len);
+        const long fr = fbase + (long)s * dt;
+        fill = load_step(s + AHEAD);
 
-        const float rg = cur_in.r, z = cur_in.z, n = cur_in.n, hn = cur_in.hn;
-        const float dht = dh + cur_in.dyv;
+        const float rg = ci.r, z = ci.z, n = ci.n, hn = ci.hn;
+        const float dht = dh + ci.dyv;
         const float dn = dht * (1.f - z);
-        const float dz = dht * ((cur_in.has_prev ? cur_in.hprev : 0.f) - n);
+        const float dz = dht * ((ci.has_prev ? ci.hprev : 0.f) - n);
         const float dnt = dn * (1.f - n * n);
         const float g_r = dnt * hn * rg * (1.f - rg);
         const float g_z = dz * z * (1.f - z);
@@ -464,9 +485,38 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x124>{});              // row_ror 4
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x128>{});              // row_ror 8
         dh = dht * z + acc;
-        cur_in = nxt;
-        fr += dt;
         // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    };
+    if constexpr (AHEAD == 1) {
+        In a = load_step(0), bnx;
+        for (int s = 0; s < len; ++s) {
+            step(s, a, bnx);
+            a = bnx;
+        }
+    } else if constexpr (AHEAD == 3) {
+        In a = load_step(0), bq = load_step(1), c = load_step(2), d;
+        int s = 0;
+        for (; s + 3 < len; s += 4) {
+            step(s, a, d);
+            step(s + 1, bq, a);
+            step(s + 2, c, bq);
+            step(s + 3, d, c);
+        }
+        if (s < len) step(s, a, d);
+        if (s + 1 < len) step(s + 1, bq, a);
+        if (s + 2 < len) step(s + 2, c, bq);
+    } else {
+        // Two steps of look-ahead: three operand sets whose roles rotate by NAME through a loop unrolled by three (a
+        // register-to-register rotation would be a consumer of the newest loads and bring their wait back to this step)
+        In a = load_step(0), bq = load_step(1), c;
+        int s = 0;
+        for (; s + 2 < len; s += 3) {
+            step(s, a, c);
+            step(s + 1, bq, a);
+            step(s + 2, c, bq);
+        }
+        if (s < len) step(s, a, c);
+        if (s + 1 < len) step(s + 1, bq, a);
     }
     if constexpr (TOK) {
         __syncthreads();
@@ -501,18 +551,25 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, nd);
     const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
+    static const int ahead = getenv("AS_GRU_AHEAD") ? atoi(getenv("AS_GRU_AHEAD")) : 2;   // look-ahead of the operand loads (steps)
 #define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
-    hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens,       \
-                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd)
+    do {                                                                                                                  \
+        if (ahead == 1)                                                                                                   \
+            hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 1>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
+                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd);                                   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
+                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd);                                   \
+    } while (0)
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
     else if (gates) AS_GRU_LAUNCH(HH, true, false);         \
     else if (tokens) AS_GRU_LAUNCH(HH, false, true);        \
-    else AS_GRU_LAUNCH(HH, false, false);
+    else AS_GRU_LAUNCH(HH, false, false)
     switch (H) {
-        case 32: AS_GRU_FWD(32) break;
-        case 64: AS_GRU_FWD(64) break;
-        case 128: AS_GRU_FWD(128) break;
+        case 32: AS_GRU_FWD(32); break;
+        case 64: AS_GRU_FWD(64); break;
+        case 128: AS_GRU_FWD(128); break;
         default:
             as_set_error("as_gru_fwd: hidden size %d not in {32, 64, 128}", H);
             return AS_ERR_UNSUPPORTED;
@@ -544,19 +601,24 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
     dim3 grid(B, 2);
     static const bool unit_layout = getenv("AS_GRU_BWD_UNIT") != nullptr;  // ablation: the 4-lanes-per-unit layout
     const size_t shm = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
+    static const int ahead = getenv("AS_GRU_AHEAD") ? atoi(getenv("AS_GRU_AHEAD")) : 2;   // look-ahead of the operand loads (steps)
+#define AS_GRU_BWD_ROW(HH, TK, AH)                                                                                            \
+    do {                                                                                                                      \
+        if (TK) {                                                                                                             \
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_row_kernel<HH, TK, AH>), \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, AS_GRU_TOK_LDS_MAX); \
+            AS_REQUIRE(attr == hipSuccess, (int)attr, "as_gru_bidir_bwd: cannot reserve LDS: %s", hipGetErrorString(attr));   \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), TK ? shm : 0, st, dy, y, gates, w_hh,        \
+                           lengths, T, dgi, dgh, g_gru_dbg, tokens, (long)tok_stride, V, part);                               \
+    } while (0)
 #define AS_GRU_BWD(HH)                                                                                                        \
     if (tokens) {                                                                                                             \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_row_kernel<HH, true>),       \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, AS_GRU_TOK_LDS_MAX);   \
-        AS_REQUIRE(attr == hipSuccess, (int)attr, "as_gru_bidir_bwd: cannot reserve LDS: %s", hipGetErrorString(attr));       \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, true>), grid, dim3(4 * HH), shm, st, dy, y, gates, w_hh, lengths, T, dgi,  \
-                           dgh, g_gru_dbg, tokens, (long)tok_stride, V, part);                                                 \
+        if (ahead == 3) AS_GRU_BWD_ROW(HH, true, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, true, 2); else AS_GRU_BWD_ROW(HH, true, 1); \
     } else if (unit_layout)                                                                                                   \
         hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
                            T, dgi, dgh);                                                                                      \
-    else                                                                                                                      \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, false>), grid, dim3(4 * HH), 0, st, dy, y, gates, w_hh, lengths, T, dgi,   \
-                           dgh, g_gru_dbg, nullptr, 0L, 0, nullptr)
+    else if (ahead == 3) AS_GRU_BWD_ROW(HH, false, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, false, 2); else AS_GRU_BWD_ROW(HH, false, 1)
     switch (H) {
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
@@ -566,6 +628,7 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
             return AS_ERR_UNSUPPORTED;
     }
 #undef AS_GRU_BWD
+#undef AS_GRU_BWD_ROW
     AS_LAUNCH_CHECK("as_gru_bidir_bwd");
     return 0;
 }
