@@ -65,24 +65,26 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
     float* yb = y + dir * H + j;                    // + frame * 2H
     float* gb = gates + (long)dir * 5 * H + j;      // + frame * 10H, planes i, f, g, o, c' at + plane * H   (TRAIN)
     const float* gib = gi + (long)dir * 4 * H + j;  // + row * 8H
-    long fr = (long)b * T + t0;
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
 
     float cst = 0.f;
-    float x[4];
-    {
-        const float* p = gib + (TOK ? (long)tok_s[t0] : fr) * 8 * H;
+    struct Gi { float x[4]; };
+    // input projection of step u (clamped to the last step: the look-ahead stays inside the sequence)
+    auto load_step = [&](int u) {
+        const int uc = u < len ? u : len - 1;
+        const int tu = t0 + uc * dt;
+        const float* p = gib + (TOK ? (long)tok_s[tu] : (long)b * T + tu) * 8 * H;
+        Gi v;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) x[g] = p[g * H];
-    }
-    int t = t0;
-    for (int s = 0; s < len; ++s) {
+        for (int g = 0; g < 4; ++g) v.x[g] = p[g * H];
+        return v;
+    };
+    // One recurrent step: consumes `ci` (loaded two steps ago), starts the loads of step s + 2 into `fill` (gru.hip: the
+    // operand sets rotate by NAME through a loop unrolled by three, so that nothing consumes a load in the step that issued it)
+    auto step = [&](int s, const Gi& ci, Gi& fill) {
         const int cur = s & 1;
-        const int adv = s + 1 < len ? dt : 0;  // look-ahead stays inside the sequence on the last step
-        const float* pn = gib + (TOK ? (long)tok_s[t + adv] : fr + adv) * 8 * H;
-        float xn[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xn[g] = pn[g * H];
+        const long fr = (long)b * T + t0 + (long)s * dt;
+        fill = load_step(s + 2);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
         f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -104,10 +106,10 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
                     }
                 }
         }
-        const float gi_ = as_sigmoid(x[0] + (quad_sum(a[0].x + a[0].y) + bh[0]));
-        const float gf = as_sigmoid(x[1] + (quad_sum(a[1].x + a[1].y) + bh[1]));
-        const float gg = as_tanh(x[2] + (quad_sum(a[2].x + a[2].y) + bh[2]));
-        const float go = as_sigmoid(x[3] + (quad_sum(a[3].x + a[3].y) + bh[3]));
+        const float gi_ = as_sigmoid(ci.x[0] + (quad_sum(a[0].x + a[0].y) + bh[0]));
+        const float gf = as_sigmoid(ci.x[1] + (quad_sum(a[1].x + a[1].y) + bh[1]));
+        const float gg = as_tanh(ci.x[2] + (quad_sum(a[2].x + a[2].y) + bh[2]));
+        const float go = as_sigmoid(ci.x[3] + (quad_sum(a[3].x + a[3].y) + bh[3]));
         cst = gf * cst + gi_ * gg;
         const float hnew = go * as_tanh(cst);
         hbuf[cur ^ 1][j] = hnew;  // the lanes of a unit hold identical values: all store the same word
@@ -117,12 +119,17 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
             gb[fr * 10 * H + q * H] = __int_as_float(gv);
             gb[fr * 10 * H + 4 * H] = cst;
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) x[g] = xn[g];
-        fr += dt;
-        t += dt;
         __syncthreads();
+    };
+    Gi a = load_step(0), bq = load_step(1), c;
+    int s = 0;
+    for (; s + 2 < len; s += 3) {
+        step(s, a, c);
+        step(s + 1, bq, a);
+        step(s + 2, c, bq);
     }
+    if (s < len) step(s, a, c);
+    if (s + 1 < len) step(s + 1, bq, a);
 }
 
 template <int H>
@@ -259,32 +266,37 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_row_kernel(const float* __rest
     const float* dyb = dy + dir * H + k;                     // + frame * 2H
     float* dgb = dg + (long)dir * 4 * H + pl * H + k;        // + frame * 8H
     const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl == 2 ? -1 : 0, m3 = pl == 3 ? -1 : 0;
-    struct In { float i, f, g, o, c, cprev, dyv; };
+    // nothing in `load` may consume a loaded value (gru.hip): has_prev is applied where cprev is used
+    struct In { float i, f, g, o, c, cprev, dyv; bool has_prev; };
     auto load = [&](long fr, bool has_prev) {
         In v;
         const float* gp = gtb + fr * 10 * H;
         v.i = gp[0]; v.f = gp[H]; v.g = gp[2 * H]; v.o = gp[3 * H]; v.c = gp[4 * H];
-        const float cp = gtb[(fr + (has_prev ? dt : 0)) * 10 * H + 4 * H];
-        v.cprev = has_prev ? cp : 0.f;
+        v.cprev = gtb[(fr + (has_prev ? dt : 0)) * 10 * H + 4 * H];
+        v.has_prev = has_prev;
         v.dyv = dyb[fr * 2 * H];
         return v;
     };
     auto dpp_add = [](float acc, float v, auto ctrl) {
         return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, true));
     };
-    long fr = (long)b * T + t0;
+    const long fbase = (long)b * T + t0;   // frame of step u: fbase + u * dt
     float dh = 0.f, dc = 0.f;
-    In cur_in = load(fr, len > 1);
-    for (int s = 0; s < len; ++s) {
+    auto load_step = [&](int u) {
+        const int uc = u < len ? u : len - 1;
+        return load(fbase + (long)uc * dt, uc + 1 < len);
+    };
+    // One step: consumes `cur_in` (loaded two steps ago), starts the loads of step s + 2 into `fill`
+    auto step = [&](int s, const In& cur_in, In& fill) {
         const int cur = s & 1;
-        const int adv = s + 1 < len ? dt : 0;
-        const In nxt = load(fr + adv, s + 2 < len);
+        const long fr = fbase + (long)s * dt;
+        fill = load_step(s + 2);
         const float dht = dh + cur_in.dyv;
         const float tc = as_tanh(cur_in.c);
         const float dct = dc + dht * cur_in.o * (1.f - tc * tc);
         const float p_o = dht * tc * cur_in.o * (1.f - cur_in.o);
         const float p_i = dct * cur_in.g * cur_in.i * (1.f - cur_in.i);
-        const float p_f = dct * cur_in.cprev * cur_in.f * (1.f - cur_in.f);
+        const float p_f = dct * (cur_in.has_prev ? cur_in.cprev : 0.f) * cur_in.f * (1.f - cur_in.f);
         const float p_g = dct * cur_in.i * (1.f - cur_in.g * cur_in.g);
         dc = dct * cur_in.f;
         const float v = __int_as_float((__float_as_int(p_i) & m0) | (__float_as_int(p_f) & m1) | (__float_as_int(p_g) & m2) |
@@ -314,10 +326,17 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_row_kernel(const float* __rest
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x124>{});              // row_ror 4
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x128>{});              // row_ror 8
         dh = acc;
-        cur_in = nxt;
-        fr += dt;
         // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+    };
+    In a = load_step(0), bq = load_step(1), c;
+    int s = 0;
+    for (; s + 2 < len; s += 3) {
+        step(s, a, c);
+        step(s + 1, bq, a);
+        step(s + 2, c, bq);
     }
+    if (s < len) step(s, a, c);
+    if (s + 1 < len) step(s + 1, bq, a);
 }
 
 }  // namespace
