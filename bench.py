@@ -85,8 +85,8 @@ def phase_bytes(rows):
     }
 
 
-GRU_BWD_KERNEL = "gru_bwd_row_kernel<128, false>"      # layer 1 (rocprofv3's name); layer 0 runs the token-sum variant
-GRU_BWD_TOK_KERNEL = "gru_bwd_row_kernel<128, true>"
+GRU_BWD_KERNEL = "gru_bwd_row_kernel<128, false, 2>"   # layer 1 (rocprofv3's name); layer 0 runs the token-sum variant
+GRU_BWD_TOK_KERNEL = "gru_bwd_row_kernel<128, true, 2>"
 
 
 def pmc_traffic(kernel):
