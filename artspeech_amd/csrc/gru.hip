@@ -14,7 +14,10 @@
 //     every ds_read_b128 is a conflict-free broadcast; reads are issued ahead of the FMAs in batches of 8;
 //   * the three gate dot products are finished with DPP quad permutes (no LDS round trip);
 //   * everything that does not depend on the recurrence (input projections, saved gates, upstream
-//     gradients) is loaded ONE STEP AHEAD, and the loop body is branch-free (redundant quad lanes store
+//     gradients) is loaded TWO STEPS AHEAD into three operand sets whose roles rotate by NAME through a
+//     loop unrolled by three: nothing may consume a loaded value in the step that issued the load -- not
+//     even a register-to-register rotation, which made every load return within one step (0.55 us, about
+//     one HBM round trip): +30-45 ns per step.  The loop body is branch-free (redundant quad lanes store
 //     the same word) so that hipcc can count its loads and never waits for the step's own stores;
 //   * the input projections (time-parallel, W_ih x + b_ih) come precomputed; for layer 0 they are a
 //     [V] row table (embedding folded into W_ih) gathered by token id through an LDS copy of the ids.

@@ -2,7 +2,7 @@
 // used by principal_components/models/rnn.py:58-68) as persistent kernels, same design as gru.hip: one workgroup per
 // (utterance, direction) walks its own sequence (packed-sequence semantics for free), W_hh (4H x H) lives in registers
 // spread over 4 lanes per hidden unit (128 weight VGPRs per lane at H = 128), h_{t-1} in double-buffered LDS with one
-// barrier per step, dot products finished with DPP quad permutes, inputs of the next step loaded one step ahead.
+// barrier per step, dot products finished with DPP quad permutes, operands loaded two steps ahead (three name-rotated sets, gru.hip).
 //   i = s(gi_i + W_hi h + b_hi)  f = s(gi_f + ...)  g = tanh(gi_g + ...)  o = s(gi_o + ...)     (gate row order i, f, g, o)
 //   c' = f c + i g,  h' = o tanh(c')
 // The forward keeps i, f, g, o and c' per frame for the backward; the backward emits the pre-activation gradients (one
