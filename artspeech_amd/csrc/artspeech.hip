@@ -293,10 +293,17 @@ int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t ro
     AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
     AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
     AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
-    // unfold the LayerNorm affines
-    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw3f, G + L.b3, P + L.w3, P + L.ln3_g, P + L.ln3_b, G + L.w3, G + L.ln3_g, G + L.ln3_b, A, O, D, st));
-    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw2f, G + L.b2, P + L.w2, P + L.ln2_g, P + L.ln2_b, G + L.w2, G + L.ln2_g, G + L.ln2_b, A, D, D, st));
-    AS_STEP("headb.unfold", st, as_unfold(ws + w.dw1f, G + L.b1, P + L.w1, P + L.ln1_g, P + L.ln1_b, G + L.w1, G + L.ln1_g, G + L.ln1_b, A, D, H, st));
+    // unfold the LayerNorm affines: the three layers in one launch
+    const float* const dWf[3] = {ws + w.dw3f, ws + w.dw2f, ws + w.dw1f};
+    const float* const dbf[3] = {G + L.b3, G + L.b2, G + L.b1};
+    const float* const Wp[3] = {P + L.w3, P + L.w2, P + L.w1};
+    const float* const gm[3] = {P + L.ln3_g, P + L.ln2_g, P + L.ln1_g};
+    const float* const bt[3] = {P + L.ln3_b, P + L.ln2_b, P + L.ln1_b};
+    float* const dWo[3] = {G + L.w3, G + L.w2, G + L.w1};
+    float* const dgm[3] = {G + L.ln3_g, G + L.ln2_g, G + L.ln1_g};
+    float* const dbt[3] = {G + L.ln3_b, G + L.ln2_b, G + L.ln1_b};
+    const int Rs[3] = {O, D, D}, Ks[3] = {D, D, H};
+    AS_STEP("headb.unfold", st, as_unfold3(dWf, dbf, Wp, gm, bt, dWo, dgm, dbt, Rs, Ks, A, st));
     return 0;
 }
 

@@ -154,11 +154,16 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, 
 //      dbeta[k] = sum_n dbf[n] W[n][k]      (chain rule through W' = W.diag(gamma), b' = b + W.beta)
 // grid (ceil(K/64), heads); block 1024 = 16 row-lanes x 64 columns (few, small matrices: favour
 // parallelism per block over block count)
-__global__ __launch_bounds__(1024) void unfold_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
-                                                      const float* __restrict__ W, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta,
-                                                      float* __restrict__ dW, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta, int R, int K) {
+struct UnfoldJob {
+    const float* dWf; const float* dbf; const float* W; const float* gamma; const float* beta;
+    float* dW; float* dgamma; float* dbeta; int R, K;
+};
+struct UnfoldJobs { UnfoldJob j[3]; };
+
+__device__ __forceinline__ void unfold_body(const float* __restrict__ dWf, const float* __restrict__ dbf,
+                                            const float* __restrict__ W, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* __restrict__ dW,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K) {
     __shared__ float r1[16][64], r2[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane;
@@ -185,6 +190,20 @@ __global__ __launch_bounds__(1024) void unfold_kernel(const float* __restrict__ 
         dgamma[head * K + k] = a;
         dbeta[head * K + k] = b;
     }
+}
+__global__ __launch_bounds__(1024) void unfold_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
+                                                      const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ dW, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int R, int K) {
+    unfold_body(dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, K);
+}
+// the three LayerNorm affines of a head stack in ONE launch (blockIdx.z = layer): each is a handful of workgroups that
+// live on memory latency, 7-10 us apiece when launched one after the other behind the weight-gradient GEMMs
+__global__ __launch_bounds__(1024) void unfold3_kernel(UnfoldJobs jobs) {
+    const UnfoldJob& j = jobs.j[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= j.K) return;   // workgroup-uniform: the grid is sized for the widest layer
+    unfold_body(j.dWf, j.dbf, j.W, j.gamma, j.beta, j.dW, j.dgamma, j.dbeta, j.R, j.K);
 }
 
 // ---- out[v][:] = sum over rows m with token(m) == v of x[m][:]   (x [rows][C]) ---------------------
@@ -683,6 +702,19 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
               float* dgamma, float* dbeta, int heads, int R, int K, hipStream_t st) {
     hipLaunchKernelGGL(unfold_kernel, dim3(as_cdiv(K, 64), heads), dim3(1024), 0, st, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, K);
     AS_LAUNCH_CHECK("unfold");
+    return 0;
+}
+int as_unfold3(const float* const dWf[3], const float* const dbf[3], const float* const W[3], const float* const gamma[3],
+               const float* const beta[3], float* const dW[3], float* const dgamma[3], float* const dbeta[3], const int R[3],
+               const int K[3], int heads, hipStream_t st) {
+    UnfoldJobs jobs;
+    int kmax = 0;
+    for (int i = 0; i < 3; ++i) {
+        jobs.j[i] = UnfoldJob{dWf[i], dbf[i], W[i], gamma[i], beta[i], dW[i], dgamma[i], dbeta[i], R[i], K[i]};
+        kmax = K[i] > kmax ? K[i] : kmax;
+    }
+    hipLaunchKernelGGL(unfold3_kernel, dim3(as_cdiv(kmax, 64), heads, 3), dim3(1024), 0, st, jobs);
+    AS_LAUNCH_CHECK("unfold3");
     return 0;
 }
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
