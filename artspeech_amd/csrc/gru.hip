@@ -53,7 +53,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
     constexpr int NT = LPU * H;   // threads
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
-    extern __shared__ int tok_s[];  // TOK: token id of every frame of this utterance
+    extern __shared__ int tok_s[];  // TOK: element offset of every frame's row in the token table (token id x row stride)
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, j = tid / LPU, q = tid % LPU;
     const int len = lengths[b];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         y[((long)b * T + i / H) * nd * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
-        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
+        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t] * (nd * 3 * H);
     __syncthreads();
     if (len <= 0) return;
 
@@ -98,8 +98,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     auto load_step = [&](int u) {
         const int uc = u < len ? u : len - 1;
         const int tu = t0 + uc * dt;
-        const long row = TOK ? (long)tok_s[tu] : (long)b * T + tu;
-        const float* p = gib + row * is;
+        const float* p = gib + (TOK ? (long)tok_s[tu] : ((long)b * T + tu) * is);
         return Gi{p[0], p[H], p[2 * H]};
     };
     // One recurrent step: consumes `ci` (loaded AHEAD steps ago) and starts the loads of step s + AHEAD into `fill`.

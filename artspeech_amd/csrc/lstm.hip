@@ -56,7 +56,7 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
         y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
-        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t];
+        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t] * (8 * H);   // element offset of the row
     __syncthreads();
     if (len <= 0) return;
 
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
     auto load_step = [&](int u) {
         const int uc = u < len ? u : len - 1;
         const int tu = t0 + uc * dt;
-        const float* p = gib + (TOK ? (long)tok_s[tu] : (long)b * T + tu) * 8 * H;
+        const float* p = gib + (TOK ? (long)tok_s[tu] : ((long)b * T + tu) * 8 * H);
         Gi v;
 #pragma unroll
         for (int g = 0; g < 4; ++g) v.x[g] = p[g * H];
