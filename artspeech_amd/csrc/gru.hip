@@ -53,7 +53,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
     constexpr int NT = LPU * H;   // threads
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
-    extern __shared__ int tok_s[];  // TOK: element offset of every frame's row in the token table (token id x row stride)
+    extern __shared__ int tok_s[];  // TOK: BYTE offset of every frame's row in the token table (token id x row stride)
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, j = tid / LPU, q = tid % LPU;
     const int len = lengths[b];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         y[((long)b * T + i / H) * nd * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
-        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t] * (nd * 3 * H);
+        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t] * (nd * 3 * H * 4);   // bytes
     __syncthreads();
     if (len <= 0) return;
 
@@ -85,10 +85,16 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     // re-deriving them from t (the address arithmetic otherwise rivals the FMAs in issue slots).
     const int t0 = dir ? len - 1 : 0;
     const int dt = dir ? -1 : 1;
-    float* yb = y + dir * H + j;                     // + frame * nd*H
-    float* gb = gates + (long)dir * 4 * H + j;       // + frame * nd*4H, planes r, z, n, hn at + plane * H   (TRAIN)
-    const float* gib = gi + (long)dir * 3 * H + j;   // + row * nd*3H
-    const long ys = (long)nd * H, gs = (long)nd * 4 * H, is = (long)nd * 3 * H;
+    // Addresses as UNIFORM base pointer (SGPR pair) + 32-bit BYTE offset (one VGPR): the loads / stores then take the
+    // scalar-base form and a step's address arithmetic is one scalar multiply and one vector add per access, instead of
+    // 64-bit vector shifts and adds.  (Every array here is far below 4 GB: checked by the launcher.)
+    const unsigned ys = (unsigned)nd * H * 4u, gs = (unsigned)nd * 4u * H * 4u, is = (unsigned)nd * 3u * H * 4u;   // bytes per frame
+    const unsigned yo = (unsigned)(dir * H + j) * 4u;                       // + frame * ys
+    const unsigned go = (unsigned)(dir * 4 * H + j + (LPU == 4 ? q * H : q * H)) * 4u;   // + frame * gs: this lane's plane
+    const unsigned io = (unsigned)(dir * 3 * H + j) * 4u;                   // + row offset (bytes)
+    const char* gi_c = reinterpret_cast<const char*>(gi);
+    char* y_c = reinterpret_cast<char*>(y);
+    char* g_c = reinterpret_cast<char*>(gates);
     // the LPU lanes of a unit hold identical gate values: lane q stores planes q, q + LPU, ... (branch-free selects)
     const int m0 = q == 0 ? -1 : 0, m1 = q == 1 ? -1 : 0, m2 = q == 2 ? -1 : 0, m3 = q == 3 ? -1 : 0;
 
@@ -98,13 +104,14 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     auto load_step = [&](int u) {
         const int uc = u < len ? u : len - 1;
         const int tu = t0 + uc * dt;
-        const float* p = gib + (TOK ? (long)tok_s[tu] : ((long)b * T + tu) * is);
+        const unsigned ro = (TOK ? (unsigned)tok_s[tu] : (unsigned)(b * T + tu) * is) + io;
+        const float* p = reinterpret_cast<const float*>(gi_c + ro);
         return Gi{p[0], p[H], p[2 * H]};
     };
     // One recurrent step: consumes `ci` (loaded AHEAD steps ago) and starts the loads of step s + AHEAD into `fill`.
     auto step = [&](int s, const Gi& ci, Gi& fill) {
         const int cur = s & 1;
-        const long fr = (long)b * T + t0 + (long)s * dt;   // frame of this step
+        const unsigned fr = (unsigned)(b * T + t0 + s * dt);   // frame of this step (wave-uniform)
         fill = load_step(s + AHEAD);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
         f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
@@ -137,17 +144,18 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         h = hnew;
         // the lanes of a unit hold identical values: all of them store (same word) -> no divergence
         hbuf[cur ^ 1][j] = hnew;
-        yb[fr * ys] = hnew;
+        *reinterpret_cast<float*>(y_c + (fr * ys + yo)) = hnew;
         if (TRAIN) {
+            float* gp = reinterpret_cast<float*>(g_c + (fr * gs + go));
             if (LPU == 4) {
                 const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
                                (__float_as_int(hn) & m3);
-                gb[fr * gs + q * H] = __int_as_float(gv);
+                gp[0] = __int_as_float(gv);
             } else {  // two lanes per unit: lane 0 stores r and n, lane 1 stores z and hn
                 const int ga = (__float_as_int(r) & m0) | (__float_as_int(z) & m1);
                 const int gc = (__float_as_int(n) & m0) | (__float_as_int(hn) & m1);
-                gb[fr * gs + q * H] = __int_as_float(ga);
-                gb[fr * gs + (2 + q) * H] = __int_as_float(gc);
+                gp[0] = __int_as_float(ga);
+                gp[2 * H] = __int_as_float(gc);
             }
         }
         __syncthreads();
@@ -550,6 +558,7 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
     AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_gru_fwd: null pointer");
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_fwd: B=%d T=%d", B, T);
     AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_gru_fwd: T=%d > 32768 with a token table", T);
+    AS_REQUIRE((long)B * T * nd * 4 * H * 4 < (1L << 32), AS_ERR_UNSUPPORTED, "as_gru_fwd: B*T=%ld frames exceed the 32-bit offsets", (long)B * T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, nd);
     const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
