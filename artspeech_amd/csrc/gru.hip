@@ -377,21 +377,25 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
 
     const int t0 = dir ? 0 : len - 1;  // opposite to the forward walk
     const int dt = dir ? 1 : -1;
-    const float* gtb = gates + (long)dir * 4 * H + k;   // + frame * 8H, planes at +0, +H, +2H, +3H
-    const float* yb = y + dir * H + k;                   // + frame * 2H
-    const float* dyb = dy + dir * H + k;                 // + frame * 2H
+    // uniform base pointer + 32-bit BYTE offset per access (gru_fwd_kernel): frames count < 2^32 / (8H * 4), checked by the launcher
+    const char* g_c = reinterpret_cast<const char*>(gates);
+    const char* y_c = reinterpret_cast<const char*>(y);
+    const char* dy_c = reinterpret_cast<const char*>(dy);
+    char* dgi_c = reinterpret_cast<char*>(dgi);
+    char* dgh_c = reinterpret_cast<char*>(dgh);
+    const unsigned gto = (unsigned)(dir * 4 * H + k) * 4u;   // + frame * 8H * 4; planes at +0, +H, +2H, +3H floats
+    const unsigned yo = (unsigned)(dir * H + k) * 4u;        // + frame * 2H * 4   (y and dy)
     const int sel = pl < 2 ? pl : 2;                     // planes r, z, n; rows 2 and 3 of the quad store the same n word
-    float* dgib = dgi + (long)dir * 3 * H + sel * H + k;  // + frame * 6H
-    float* dghb = dgh + (long)dir * 3 * H + sel * H + k;
-    const int m0 = pl == 0 ? -1 : 0, m1 = pl == 1 ? -1 : 0, m2 = pl >= 2 ? -1 : 0;
+    const unsigned dgo = (unsigned)(dir * 3 * H + sel * H + k) * 4u;   // + frame * 6H * 4   (dgi and dgh)
     struct In { float r, z, n, hn, hprev, dyv; bool has_prev; };
     auto load = [&](long fr, bool has_prev) {
         In v;
-        const float* gp = gtb + fr * 8 * H;
+        const unsigned f = (unsigned)fr;
+        const float* gp = reinterpret_cast<const float*>(g_c + (f * (8u * H * 4u) + gto));
         v.r = gp[0]; v.z = gp[H]; v.n = gp[2 * H]; v.hn = gp[3 * H];
-        v.hprev = yb[(fr + (has_prev ? dt : 0)) * 2 * H];
+        v.hprev = *reinterpret_cast<const float*>(y_c + ((f + (unsigned)(has_prev ? dt : 0)) * (2u * H * 4u) + yo));
         v.has_prev = has_prev;
-        v.dyv = dyb[fr * 2 * H];
+        v.dyv = *reinterpret_cast<const float*>(dy_c + (f * (2u * H * 4u) + yo));
         return v;
     };
     // Reduce-scatter of the four partial sums over the 16 lanes of a DPP row: the lane at quad position qp needs only the
@@ -431,12 +435,13 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         const float g_r = dnt * hn * rg * (1.f - rg);
         const float g_z = dz * z * (1.f - z);
         const float g_hn = dnt * rg;
-        const int rz = (__float_as_int(g_r) & m0) | (__float_as_int(g_z) & m1);
-        const float vi = __int_as_float(rz | (__float_as_int(dnt) & m2));
-        const float vh = __int_as_float(rz | (__float_as_int(g_hn) & m2));
+        const float rz = pl == 0 ? g_r : g_z;       // lanes of planes r, z, n (two of them): three selects on loop-invariant masks
+        const float vi = pl >= 2 ? dnt : rz;
+        const float vh = pl >= 2 ? g_hn : rz;
         gbuf[cur][sel * H + k] = vh;
-        if constexpr (!TOK) dgib[fr * 6 * H] = vi;
-        dghb[fr * 6 * H] = vh;
+        const unsigned dfo = (unsigned)fr * (6u * H * 4u) + dgo;
+        if constexpr (!TOK) *reinterpret_cast<float*>(dgi_c + dfo) = vi;
+        *reinterpret_cast<float*>(dgh_c + dfo) = vh;
         __syncthreads();
 
         f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -608,6 +613,7 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
     AS_REQUIRE(dy && y && gates && w_hh && lengths && (dgi || tokens) && dgh, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: null pointer");
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_bidir_bwd: B=%d T=%d", B, T);
     AS_REQUIRE(!tokens || (part && V > 0 && tok_stride >= T), AS_ERR_BAD_ARG, "as_gru_bidir_bwd: token table arguments");
+    AS_REQUIRE((long)B * T * 8 * H * 4 < (1L << 32), AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: B*T=%ld frames exceed the 32-bit offsets", (long)B * T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
     static const bool unit_layout = getenv("AS_GRU_BWD_UNIT") != nullptr;  // ablation: the 4-lanes-per-unit layout
