@@ -52,7 +52,9 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
     constexpr int CW = 4 * LPU;   // floats of the reduction index covered by one ds_read_b128 of every lane of a unit
     constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
     constexpr int NT = LPU * H;   // threads
-    __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    // THREE buffers for h, indexed by the step's position in the loop that is unrolled by three: the LDS addresses of the
+    // read (buffer d) and of the write (buffer d + 1) are then constants of each unrolled copy
+    __shared__ __attribute__((aligned(16))) float hbuf[3][H];
     extern __shared__ int tok_s[];  // TOK: BYTE offset of every frame's row in the token table (token id x row stride)
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, j = tid / LPU, q = tid % LPU;
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         return Gi{p[0], p[H], p[2 * H]};
     };
     // One recurrent step: consumes `ci` (loaded AHEAD steps ago) and starts the loads of step s + AHEAD into `fill`.
-    auto step = [&](int s, const Gi& ci, Gi& fill) {
-        const int cur = s & 1;
+    auto step = [&](auto curc, int s, const Gi& ci, Gi& fill) {
+        const int cur = curc, nxt = (cur + 1) % 3;             // buffer read / written by this step
         const unsigned fr = (unsigned)(b * T + t0 + s * dt);   // frame of this step (wave-uniform)
         fill = load_step(s + AHEAD);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
         // the lanes of a unit hold identical values: all of them store (same word) -> no divergence
-        hbuf[cur ^ 1][j] = hnew;
+        hbuf[nxt][j] = hnew;
         *reinterpret_cast<float*>(y_c + (fr * ys + yo)) = hnew;
         if (TRAIN) {
             float* gp = reinterpret_cast<float*>(g_c + (fr * gs + go));
@@ -160,10 +162,13 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         }
         __syncthreads();
     };
+    constexpr std::integral_constant<int, 0> c0{};
+    constexpr std::integral_constant<int, 1> c1{};
+    constexpr std::integral_constant<int, 2> c2{};
     if constexpr (AHEAD == 1) {
         Gi a = load_step(0), bn;
         for (int s = 0; s < len; ++s) {
-            step(s, a, bn);
+            step(s % 3, s, a, bn);
             a = bn;
         }
     } else {
@@ -173,12 +178,12 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         Gi a = load_step(0), bq = load_step(1), c;
         int s = 0;
         for (; s + 2 < len; s += 3) {
-            step(s, a, c);
-            step(s + 1, bq, a);
-            step(s + 2, c, bq);
+            step(c0, s, a, c);
+            step(c1, s + 1, bq, a);
+            step(c2, s + 2, c, bq);
         }
-        if (s < len) step(s, a, c);
-        if (s + 1 < len) step(s + 1, bq, a);
+        if (s < len) step(c0, s, a, c);
+        if (s + 1 < len) step(c1, s + 1, bq, a);
     }
 }
 
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     }
     constexpr int VW = VL % 4 == 0 ? 4 : 2;   // floats per LDS read
     constexpr int NCH = VL / VW;              // LDS reads per lane per step
-    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
+    __shared__ __attribute__((aligned(16))) float gbuf[3][3 * H];   // three buffers: index = position in the loop unrolled by three
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, row = tid >> 4, r = tid & 15;
     const int k0 = row * 4, k = k0 + (r & 3), pl = r >> 2;
@@ -422,8 +427,8 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         return load(fbase + (long)uc * dt, uc + 1 < len);
     };
     // One recurrent step: consumes `ci` (loaded AHEAD steps ago), starts the loads of step s + AHEAD into `fill`.
-    auto step = [&](int s, const In& ci, In& fill) {
-        const int cur = s & 1;
+    auto step = [&](auto curc, int s, const In& ci, In& fill) {
+        const int cur = curc;
         const long fr = fbase + (long)s * dt;
         fill = load_step(s + AHEAD);
 
@@ -500,38 +505,41 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x124>{});              // row_ror 4
         acc = dpp_add(acc, acc, std::integral_constant<int, 0x128>{});              // row_ror 8
         dh = dht * z + acc;
-        // gbuf is double buffered: the next step writes gbuf[cur^1], whose readers all passed the barrier above
+        // the next step writes another buffer of gbuf, whose readers all passed the barrier above: one barrier per step
     };
+    constexpr std::integral_constant<int, 0> c0{};
+    constexpr std::integral_constant<int, 1> c1{};
+    constexpr std::integral_constant<int, 2> c2{};
     if constexpr (AHEAD == 1) {
         In a = load_step(0), bnx;
         for (int s = 0; s < len; ++s) {
-            step(s, a, bnx);
+            step(s % 3, s, a, bnx);
             a = bnx;
         }
     } else if constexpr (AHEAD == 3) {
         In a = load_step(0), bq = load_step(1), c = load_step(2), d;
         int s = 0;
         for (; s + 3 < len; s += 4) {
-            step(s, a, d);
-            step(s + 1, bq, a);
-            step(s + 2, c, bq);
-            step(s + 3, d, c);
+            step(s % 3, s, a, d);
+            step((s + 1) % 3, s + 1, bq, a);
+            step((s + 2) % 3, s + 2, c, bq);
+            step((s + 3) % 3, s + 3, d, c);
         }
-        if (s < len) step(s, a, d);
-        if (s + 1 < len) step(s + 1, bq, a);
-        if (s + 2 < len) step(s + 2, c, bq);
+        if (s < len) step(s % 3, s, a, d);
+        if (s + 1 < len) step((s + 1) % 3, s + 1, bq, a);
+        if (s + 2 < len) step((s + 2) % 3, s + 2, c, bq);
     } else {
         // Two steps of look-ahead: three operand sets whose roles rotate by NAME through a loop unrolled by three (a
         // register-to-register rotation would be a consumer of the newest loads and bring their wait back to this step)
         In a = load_step(0), bq = load_step(1), c;
         int s = 0;
         for (; s + 2 < len; s += 3) {
-            step(s, a, c);
-            step(s + 1, bq, a);
-            step(s + 2, c, bq);
+            step(c0, s, a, c);
+            step(c1, s + 1, bq, a);
+            step(c2, s + 2, c, bq);
         }
-        if (s < len) step(s, a, c);
-        if (s + 1 < len) step(s + 1, bq, a);
+        if (s < len) step(c0, s, a, c);
+        if (s + 1 < len) step(c1, s + 1, bq, a);
     }
     if constexpr (TOK) {
         __syncthreads();
