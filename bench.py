@@ -188,8 +188,8 @@ def make_batch(n_utt, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="which run is the headline `value` (N > 1 measures both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
