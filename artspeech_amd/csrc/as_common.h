@@ -67,4 +67,7 @@ __device__ __forceinline__ double as_wave_sum_d(double v) {
 // instructions than an IEEE division on the recurrence's critical path
 __device__ __forceinline__ float as_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // tanh via one exp; no overflow (exp(+inf) -> inf -> rcp = 0 -> 1)
-__device__ __forceinline__ float as_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// (exp(2x) as ONE multiply by 2 log2(e) in front of v_exp_f32)
+__device__ __forceinline__ float as_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
+}

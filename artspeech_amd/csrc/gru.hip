@@ -72,7 +72,8 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
                 w[g][2 * c + 1] = f32x2{v.z, v.w};
             }
     }
-    const float bh_r = b_hh[dir * 3 * H + j], bh_z = b_hh[dir * 3 * H + H + j], bh_n = b_hh[dir * 3 * H + 2 * H + j];
+    const float bq_r = b_hh[dir * 3 * H + j] * (1.0f / LPU), bq_z = b_hh[dir * 3 * H + H + j] * (1.0f / LPU),
+                bq_n = b_hh[dir * 3 * H + 2 * H + j] * (1.0f / LPU);
 
     // pad_packed_sequence: outputs of padded frames are exact zeros
     for (long i = (long)len * H + tid; i < (long)T * H; i += NT)
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         const unsigned fr = (unsigned)(b * T + t0 + s * dt);   // frame of this step (wave-uniform)
         fill = load_step(s + AHEAD);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
-        f32x2 ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};
+        // the recurrent biases ride in as the accumulators' start value (1 / LPU of it in each lane of the unit: exact, LPU
+        // is a power of two), which costs nothing -- the first FMA takes a register pair instead of the literal 0
+        f32x2 ar = {bq_r, 0.f}, az = {bq_z, 0.f}, an = {bq_n, 0.f};
 #pragma unroll
         for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their FMAs (hipcc otherwise pairs them 2 by 2)
             float4 hv[8];
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
                 }
         }
         const float sr = unit_sum<LPU>(ar.x + ar.y), sz = unit_sum<LPU>(az.x + az.y), sn = unit_sum<LPU>(an.x + an.y);
-        const float r = as_sigmoid(ci.r + (sr + bh_r));
-        const float z = as_sigmoid(ci.z + (sz + bh_z));
-        const float hn = sn + bh_n;
+        const float r = as_sigmoid(ci.r + sr);
+        const float z = as_sigmoid(ci.z + sz);
+        const float hn = sn;
         const float n = as_tanh(ci.n + r * hn);
         const float hnew = (1.f - z) * n + z * h;
         h = hnew;
