@@ -430,15 +430,19 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         return load(fbase + (long)uc * dt, uc + 1 < len);
     };
     // One recurrent step: consumes `ci` (loaded AHEAD steps ago), starts the loads of step s + AHEAD into `fill`.
-    auto step = [&](auto curc, int s, const In& ci, In& fill) {
+    // bulk: step s + AHEAD + 1 exists, so neither the look-ahead's clamp nor the h_prev selects are needed (scalar compares,
+    // selects and multiplies that the general form pays on every step)
+    auto step = [&](auto bulk, auto curc, int s, const In& ci, In& fill) {
+        constexpr bool BULK = decltype(bulk)::value;
         const int cur = curc;
         const long fr = fbase + (long)s * dt;
-        fill = load_step(s + AHEAD);
+        if constexpr (BULK) fill = load(fbase + (long)(s + AHEAD) * dt, true);
+        else fill = load_step(s + AHEAD);
 
         const float rg = ci.r, z = ci.z, n = ci.n, hn = ci.hn;
         const float dht = dh + ci.dyv;
         const float dn = dht * (1.f - z);
-        const float dz = dht * ((ci.has_prev ? ci.hprev : 0.f) - n);
+        const float dz = dht * (((BULK || ci.has_prev) ? ci.hprev : 0.f) - n);
         const float dnt = dn * (1.f - n * n);
         const float g_r = dnt * hn * rg * (1.f - rg);
         const float g_z = dz * z * (1.f - z);
@@ -516,33 +520,40 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     if constexpr (AHEAD == 1) {
         In a = load_step(0), bnx;
         for (int s = 0; s < len; ++s) {
-            step(s % 3, s, a, bnx);
+            step(std::false_type{}, s % 3, s, a, bnx);
             a = bnx;
         }
     } else if constexpr (AHEAD == 3) {
         In a = load_step(0), bq = load_step(1), c = load_step(2), d;
         int s = 0;
         for (; s + 3 < len; s += 4) {
-            step(s % 3, s, a, d);
-            step((s + 1) % 3, s + 1, bq, a);
-            step((s + 2) % 3, s + 2, c, bq);
-            step((s + 3) % 3, s + 3, d, c);
+            step(std::false_type{}, s % 3, s, a, d);
+            step(std::false_type{}, (s + 1) % 3, s + 1, bq, a);
+            step(std::false_type{}, (s + 2) % 3, s + 2, c, bq);
+            step(std::false_type{}, (s + 3) % 3, s + 3, d, c);
         }
-        if (s < len) step(s % 3, s, a, d);
-        if (s + 1 < len) step((s + 1) % 3, s + 1, bq, a);
-        if (s + 2 < len) step((s + 2) % 3, s + 2, c, bq);
+        if (s < len) step(std::false_type{}, s % 3, s, a, d);
+        if (s + 1 < len) step(std::false_type{}, (s + 1) % 3, s + 1, bq, a);
+        if (s + 2 < len) step(std::false_type{}, (s + 2) % 3, s + 2, c, bq);
     } else {
         // Two steps of look-ahead: three operand sets whose roles rotate by NAME through a loop unrolled by three (a
         // register-to-register rotation would be a consumer of the newest loads and bring their wait back to this step)
         In a = load_step(0), bq = load_step(1), c;
         int s = 0;
-        for (; s + 2 < len; s += 3) {
-            step(c0, s, a, c);
-            step(c1, s + 1, bq, a);
-            step(c2, s + 2, c, bq);
+        constexpr std::true_type yes{};
+        constexpr std::false_type no{};
+        for (; s + 5 < len; s += 3) {   // every step of the group has s + AHEAD + 1 < len
+            step(yes, c0, s, a, c);
+            step(yes, c1, s + 1, bq, a);
+            step(yes, c2, s + 2, c, bq);
         }
-        if (s < len) step(c0, s, a, c);
-        if (s + 1 < len) step(c1, s + 1, bq, a);
+        for (; s + 2 < len; s += 3) {
+            step(no, c0, s, a, c);
+            step(no, c1, s + 1, bq, a);
+            step(no, c2, s + 2, c, bq);
+        }
+        if (s < len) step(no, c0, s, a, c);
+        if (s + 1 < len) step(no, c1, s + 1, bq, a);
     }
     if constexpr (TOK) {
         __syncthreads();

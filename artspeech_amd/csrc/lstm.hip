@@ -50,7 +50,7 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
     }
     float bh[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bh[g] = b_hh[dir * 4 * H + g * H + j];
+    for (int g = 0; g < 4; ++g) bh[g] = b_hh[dir * 4 * H + g * H + j] * (1.0f / LPU);   // a quarter per lane of the unit: see below
 
     for (long i = (long)len * H + tid; i < (long)T * H; i += NT)  // pad_packed_sequence: zeros at padded frames
         y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
         const long fr = (long)b * T + t0 + (long)s * dt;
         fill = load_step(s + 2);
         const float4* hp = reinterpret_cast<const float4*>(hbuf[cur]);
-        f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        // the recurrent biases ride in as the accumulators' start value (gru.hip)
+        f32x2 a[4] = {{bh[0], 0.f}, {bh[1], 0.f}, {bh[2], 0.f}, {bh[3], 0.f}};
 #pragma unroll
         for (int c0 = 0; c0 < NC; c0 += 8) {  // 8 LDS reads in flight, then their FMAs
             float4 hv[8];
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(LPU * H) void lstm_fwd_kernel(const float* __restri
                     }
                 }
         }
-        const float gi_ = as_sigmoid(ci.x[0] + (quad_sum(a[0].x + a[0].y) + bh[0]));
-        const float gf = as_sigmoid(ci.x[1] + (quad_sum(a[1].x + a[1].y) + bh[1]));
-        const float gg = as_tanh(ci.x[2] + (quad_sum(a[2].x + a[2].y) + bh[2]));
-        const float go = as_sigmoid(ci.x[3] + (quad_sum(a[3].x + a[3].y) + bh[3]));
+        const float gi_ = as_sigmoid(ci.x[0] + quad_sum(a[0].x + a[0].y));
+        const float gf = as_sigmoid(ci.x[1] + quad_sum(a[1].x + a[1].y));
+        const float gg = as_tanh(ci.x[2] + quad_sum(a[2].x + a[2].y));
+        const float go = as_sigmoid(ci.x[3] + quad_sum(a[3].x + a[3].y));
         cst = gf * cst + gi_ * gg;
         const float hnew = go * as_tanh(cst);
         hbuf[cur ^ 1][j] = hnew;  // the lanes of a unit hold identical values: all store the same word
