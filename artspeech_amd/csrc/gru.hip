@@ -439,17 +439,22 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         if constexpr (BULK) fill = load(fbase + (long)(s + AHEAD) * dt, true);
         else fill = load_step(s + AHEAD);
 
+        // Every output of the step is dht times a COEFFICIENT that depends on the saved gates only (known two steps ago):
+        //   dnt = dht (1-z)(1-n^2),  g_hn = dnt r,  g_r = dnt hn r (1-r),  g_z = dht (h_prev - n) z (1-z).
+        // The coefficients (and the choice of this lane's plane among them) are off the recurrence's dependency chain; what
+        // follows the arrival of dh is one add and two multiplies instead of a six-deep product chain.
         const float rg = ci.r, z = ci.z, n = ci.n, hn = ci.hn;
+        const float omz = 1.f - z;
+        const float c_n = omz * (1.f - n * n);
+        const float c_hn = c_n * rg;
+        const float c_r = c_hn * hn * (1.f - rg);
+        const float c_z = (((BULK || ci.has_prev) ? ci.hprev : 0.f) - n) * z * omz;
+        const float c_rz = pl == 0 ? c_r : c_z;     // lanes of planes r, z, n (two of them): selects on loop-invariant masks
+        const float c_vi = pl >= 2 ? c_n : c_rz;
+        const float c_vh = pl >= 2 ? c_hn : c_rz;
         const float dht = dh + ci.dyv;
-        const float dn = dht * (1.f - z);
-        const float dz = dht * (((BULK || ci.has_prev) ? ci.hprev : 0.f) - n);
-        const float dnt = dn * (1.f - n * n);
-        const float g_r = dnt * hn * rg * (1.f - rg);
-        const float g_z = dz * z * (1.f - z);
-        const float g_hn = dnt * rg;
-        const float rz = pl == 0 ? g_r : g_z;       // lanes of planes r, z, n (two of them): three selects on loop-invariant masks
-        const float vi = pl >= 2 ? dnt : rz;
-        const float vh = pl >= 2 ? g_hn : rz;
+        const float vi = dht * c_vi;
+        const float vh = dht * c_vh;
         gbuf[cur][sel * H + k] = vh;
         const unsigned dfo = (unsigned)fr * (6u * H * 4u) + dgo;
         if constexpr (!TOK) *reinterpret_cast<float*>(dgi_c + dfo) = vi;
