@@ -153,9 +153,11 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         if (TRAIN) {
             float* gp = reinterpret_cast<float*>(g_c + (fr * gs + go));
             if (LPU == 4) {
-                const int gv = (__float_as_int(r) & m0) | (__float_as_int(z) & m1) | (__float_as_int(n) & m2) |
-                               (__float_as_int(hn) & m3);
-                gp[0] = __int_as_float(gv);
+                // lane q stores plane q: three bitfield inserts ((a & m) | (b & ~m) is v_bfi_b32) on loop-invariant lane masks
+                const int m01 = m0 | m1;
+                const int t1 = (__float_as_int(r) & m0) | (__float_as_int(z) & ~m0);
+                const int t2 = (__float_as_int(n) & m2) | (__float_as_int(hn) & ~m2);
+                gp[0] = __int_as_float((t1 & m01) | (t2 & ~m01));
             } else {  // two lanes per unit: lane 0 stores r and n, lane 1 stores z and hn
                 const int ga = (__float_as_int(r) & m0) | (__float_as_int(z) & m1);
                 const int gc = (__float_as_int(n) & m0) | (__float_as_int(hn) & m1);
