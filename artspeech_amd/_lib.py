@@ -10,6 +10,10 @@ import torch  # noqa: F401  (must be loaded before the library: single HIP runti
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libartspeech_hip.so")
+# tools/ only: the -DAS_DIAG flavour (ablation switches, legacy kernels; `python -m artspeech_amd.build --diag`).  The
+# product library has none of them compiled in, so AS_* environment variables cannot change what it computes.
+if os.environ.get("ARTSPEECH_DIAG_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "libartspeech_hip_diag.so")
 
 c_f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 

@@ -1,5 +1,10 @@
 """Build recipe for libartspeech_hip.so (hipcc, gfx950 only).  Idempotent: sources newer than their
-object files are recompiled, then everything is linked in-tree next to this file."""
+object files are recompiled, then everything is linked in-tree next to this file.
+
+Two flavours from the same sources:
+  product (default)   libartspeech_hip.so        no ablation / tuning switch exists in it (AS_DIAG_* fold to constants)
+  diagnostic (--diag) libartspeech_hip_diag.so   -DAS_DIAG: the AS_* environment switches and legacy kernels the tools/
+                                                 use; loaded only when ARTSPEECH_DIAG_LIB=1 (artspeech_amd/_lib.py)"""
 import os
 import subprocess
 import sys
@@ -9,6 +14,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libartspeech_hip.so")
+OBJ_DIAG = os.path.join(HERE, "csrc", "build", "diag")
+LIB_DIAG = os.path.join(HERE, "libartspeech_hip_diag.so")
 
 ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
@@ -37,8 +44,10 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(s) > t for s in (src, *extra))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, diag=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    OBJ, LIB = (OBJ_DIAG, LIB_DIAG) if diag else (globals()["OBJ"], globals()["LIB"])
+    COMMON = globals()["COMMON"] + (["-DAS_DIAG"] if diag else [])
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "artspeech_hip.h"))
@@ -64,5 +73,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

@@ -323,7 +323,7 @@ struct StreamState {
 };
 int g_overlap = -1;  // -1: not decided yet (environment), 0: off, 1: on
 // AS_ONE_SIDE_STREAM (ablation): the hidden-to-hidden weight gradients queue on the first side stream (round-2 start)
-const bool g_one_side = getenv("AS_ONE_SIDE_STREAM") != nullptr;
+const bool g_one_side = AS_DIAG_SET("AS_ONE_SIDE_STREAM");
 std::mutex g_state_mu;
 std::vector<StreamState*> g_states;
 

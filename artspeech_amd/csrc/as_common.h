@@ -8,6 +8,20 @@
 
 #define AS_WAVE 64
 
+// Diagnostic switches (ablations, tuning aids, legacy kernels) exist only in the -DAS_DIAG build of the library
+// (artspeech_amd/build.py --diag -> libartspeech_hip_diag.so, used by tools/).  In the product build every switch is a
+// compile-time constant: no environment variable can change what the shipped library computes or which kernel it takes.
+#ifdef AS_DIAG
+#include <stdlib.h>
+#define AS_DIAG_SET(name) (getenv(name) != nullptr)
+#define AS_DIAG_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define AS_DIAG_STR(name) (getenv(name))
+#else
+#define AS_DIAG_SET(name) false
+#define AS_DIAG_INT(name, dflt) (dflt)
+#define AS_DIAG_STR(name) ((const char*)nullptr)
+#endif
+
 void as_set_error(const char* fmt, ...);
 
 #define AS_REQUIRE(cond, code, ...)            \

@@ -605,7 +605,7 @@ int* counters_for(hipStream_t st) {
     struct Slot { int dev; hipStream_t st; int* p; };
     static std::mutex mu;
     static std::vector<Slot> slots;
-    static const bool off = getenv("AS_GEMM_NO_FIXUP") != nullptr;  // ablation: always the separate reduce kernel
+    static const bool off = AS_DIAG_SET("AS_GEMM_NO_FIXUP");  // ablation: always the separate reduce kernel
     if (off) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -705,7 +705,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     }
     // 128x128 tiles once they fill the chip and N fills a tile (N = 100: 60 vs 72 us at 64x64), else 64x64 for more workgroups
     const long big = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
-    static const char* force = getenv("AS_GEMM_TILE");  // tuning aid: "128x128" | "64x128" | "128x64" | "64x64"
+    static const char* force = AS_DIAG_STR("AS_GEMM_TILE");  // tuning aid: "128x128" | "64x128" | "128x64" | "64x64"
     if (force && !strcmp(force, "128x128")) return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "64x128")) return launch<64, 128>(k, g->batch, a_kc, b_kc, st);
     if (force && !strcmp(force, "128x64")) return launch<128, 64>(k, g->batch, a_kc, b_kc, st);

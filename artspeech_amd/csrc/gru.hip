@@ -596,7 +596,10 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, nd);
     const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
-    static const int ahead = getenv("AS_GRU_AHEAD") ? atoi(getenv("AS_GRU_AHEAD")) : 2;   // look-ahead of the operand loads (steps)
+#ifdef AS_DIAG
+    static const int ahead = AS_DIAG_INT("AS_GRU_AHEAD", 2);   // look-ahead of the operand loads (steps)
+#endif
+#ifdef AS_DIAG   // the one-step look-ahead instantiation exists in the diagnostic build only
 #define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
     do {                                                                                                                  \
         if (ahead == 1)                                                                                                   \
@@ -606,6 +609,11 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
             hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
                                (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd);                                   \
     } while (0)
+#else
+#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                     \
+    hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
+                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd)
+#endif
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
     else if (gates) AS_GRU_LAUNCH(HH, true, false);         \
@@ -645,9 +653,13 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
     AS_REQUIRE((long)B * T * 8 * H * 4 < (1L << 32), AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: B*T=%ld frames exceed the 32-bit offsets", (long)B * T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
-    static const bool unit_layout = getenv("AS_GRU_BWD_UNIT") != nullptr;  // ablation: the 4-lanes-per-unit layout
+#ifdef AS_DIAG
+    static const bool unit_layout = AS_DIAG_SET("AS_GRU_BWD_UNIT");  // ablation: the 4-lanes-per-unit layout
+#endif
     const size_t shm = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
-    static const int ahead = getenv("AS_GRU_AHEAD") ? atoi(getenv("AS_GRU_AHEAD")) : 2;   // look-ahead of the operand loads (steps)
+#ifdef AS_DIAG
+    static const int ahead = AS_DIAG_INT("AS_GRU_AHEAD", 2);   // look-ahead of the operand loads (steps)
+#endif
 #define AS_GRU_BWD_ROW(HH, TK, AH)                                                                                            \
     do {                                                                                                                      \
         if (TK) {                                                                                                             \
@@ -658,6 +670,7 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
         hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), TK ? shm : 0, st, dy, y, gates, w_hh,        \
                            lengths, T, dgi, dgh, g_gru_dbg, tokens, (long)tok_stride, V, part);                               \
     } while (0)
+#ifdef AS_DIAG   // other look-aheads and the 4-lanes-per-unit layout exist in the diagnostic build only
 #define AS_GRU_BWD(HH)                                                                                                        \
     if (tokens) {                                                                                                             \
         if (ahead == 3) AS_GRU_BWD_ROW(HH, true, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, true, 2); else AS_GRU_BWD_ROW(HH, true, 1); \
@@ -665,6 +678,10 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
         hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
                            T, dgi, dgh);                                                                                      \
     else if (ahead == 3) AS_GRU_BWD_ROW(HH, false, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, false, 2); else AS_GRU_BWD_ROW(HH, false, 1)
+#else
+#define AS_GRU_BWD(HH) \
+    if (tokens) AS_GRU_BWD_ROW(HH, true, 2); else AS_GRU_BWD_ROW(HH, false, 2)
+#endif
     switch (H) {
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
@@ -690,7 +707,7 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
 // part [B][V][6H], instead of dgi.  0 = not a case for it (V * 3H floats must fit the LDS budget): the caller takes
 // as_gru_bidir_bwd + as_token_segsum.
 bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T) {
-    static const bool off = getenv("AS_NO_GRU_TOKSUM") != nullptr;   // ablation: dgi + the segmented-sum kernel
+    static const bool off = AS_DIAG_SET("AS_NO_GRU_TOKSUM");   // ablation: dgi + the segmented-sum kernel
     return !off && ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) <= AS_GRU_TOK_LDS_MAX;
 }
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,

@@ -41,9 +41,17 @@ struct LinK {
     const float* bias; long bias_batch;
     int M, N, K, ka_valid, batch, act;
     int n_big, big_per_batch, big_per_batch_rows, small_per_batch;   // tiles of 64 rows first, then tiles of 32 rows (see launch())
+#ifdef AS_DIAG
     int stagger;
+#else
+    static constexpr int stagger = 0;
+#endif
     unsigned long long* dbg; long dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps), normally null
+#ifdef AS_DIAG
     int abl;  // diagnostic (AS_LIN_ABL): 1 = return before the epilogue, 2 = no DMA after the prologue
+#else
+    static constexpr int abl = 0;
+#endif
     float eps;
     float* rstd;                      // EPI_LNF out: [M][batch]
     unsigned long long* bits;         // EPI_LNF out: [M][batch][4]: v > 0 per feature
@@ -342,7 +350,7 @@ int launch(const LinK& k, hipStream_t st) {
     constexpr int slots = 512;
     const long units = (long)as_cdiv(k.M, 64) * k.batch;      // work in 64-row tiles
     const long rounds = units / slots;
-    static const bool all_big = getenv("AS_LIN_ALLBIG") != nullptr;  // ablation: 64-row tiles only (+ a ragged end)
+    static const bool all_big = AS_DIAG_SET("AS_LIN_ALLBIG");  // ablation: 64-row tiles only (+ a ragged end)
     int x = (int)(rounds * slots / k.batch);                    // 64-row tiles per head that fill whole rounds
     if (x > k.M / 64 || all_big) x = k.M / 64;
     const int rest = k.M - x * 64;
@@ -370,7 +378,7 @@ extern "C" void as_lin_debug_stamps(uint64_t* buf, int64_t max_workgroups) {
 // see gemm_internal.h.  Returns 1 if launched, 0 if the arguments are outside what the kernel is built for (the caller
 // then takes the general GEMM + row kernels), < 0 on a launch error.
 int as_lin_try(const as_lin* a, hipStream_t st) {
-    static const bool off = getenv("AS_NO_LIN") != nullptr;  // ablation: the round-1 path
+    static const bool off = AS_DIAG_SET("AS_NO_LIN");  // ablation: the round-1 path
     if (off) return 0;
     if (a->K % BK || a->K < BK || a->N > BN || a->N < 4 || a->M < 1 || a->batch < 1) return 0;
     if (!aligned16(a->A) || !aligned16(a->B) || a->lda % 4 || a->ldb % 4 || a->a_batch % 4 || a->b_batch % 4) return 0;
@@ -385,10 +393,12 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     k.bias = a->bias; k.bias_batch = a->bias_batch;
     k.M = a->M; k.N = a->N; k.K = a->K; k.ka_valid = a->ka_valid > 0 ? a->ka_valid : a->K; k.batch = a->batch; k.act = a->act;
     k.eps = 1e-5f;
-    static const int abl = getenv("AS_LIN_ABL") ? atoi(getenv("AS_LIN_ABL")) : 0;
+#ifdef AS_DIAG
+    static const int abl = AS_DIAG_INT("AS_LIN_ABL", 0);
     k.abl = abl;
-    static const int stagger = getenv("AS_LIN_STAGGER") ? atoi(getenv("AS_LIN_STAGGER")) : 0;  // measured: no gain
+    static const int stagger = AS_DIAG_INT("AS_LIN_STAGGER", 0);  // measured: no gain
     k.stagger = stagger;
+#endif
     k.dbg = g_dbg; k.dbg_max = g_dbg_max;
     k.rstd = a->rstd; k.bits = a->bits;
     k.xhat = a->xhat; k.ldx = a->ldx; k.x_batch = a->x_batch; k.rstd_in = a->rstd_in; k.bits_in = a->bits_in;

@@ -377,10 +377,14 @@ extern "C" int as_lstm_bidir_bwd(const float* dy, const float* gates, const floa
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_lstm_bidir_bwd: B=%d T=%d", B, T);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B, 2);
-    static const bool unit_layout = getenv("AS_LSTM_BWD_UNIT") != nullptr;  // ablation: the older 4-lanes-per-unit layout
+#ifdef AS_DIAG
+    static const bool unit_layout = AS_DIAG_SET("AS_LSTM_BWD_UNIT");  // ablation: the older 4-lanes-per-unit layout
 #define AS_LSTM_BWD(HH)                                                                                                     \
     if (unit_layout) hipLaunchKernelGGL((lstm_bwd_kernel<HH>), grid, dim3(LPU * HH), 0, st, dy, gates, w_hh, lengths, T, dg); \
     else hipLaunchKernelGGL((lstm_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, gates, w_hh, lengths, T, dg)
+#else
+#define AS_LSTM_BWD(HH) hipLaunchKernelGGL((lstm_bwd_row_kernel<HH>), grid, dim3(4 * HH), 0, st, dy, gates, w_hh, lengths, T, dg)
+#endif
     switch (H) {
         case 32: AS_LSTM_BWD(32); break;
         case 64: AS_LSTM_BWD(64); break;

@@ -45,7 +45,11 @@ struct WgradK {
     float* slab;     // [splitk][batch][M][N]
     float* cs_slab;  // [splitk][batch][M]
     float* colsum; long colsum_batch;
+#ifdef AS_DIAG
     int abl;  // diagnostic ablation (AS_WGRAD_ABL=1): no global loads after the first two k-tiles (matrix work only)
+#else
+    static constexpr int abl = 0;
+#endif
 };
 
 // LDS-DMA helper: one wave-instruction copies 64 x 16 B from per-lane global addresses to 1 KiB of LDS starting at the
@@ -255,7 +259,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Takes the GEMM if it is a weight-gradient shape this kernel is built for (returns 1 and launches), else returns 0;
 // negative = error.  Called by as_gemm_f32 ahead of its general tile selection.
 int as_wgrad_try(const as_gemm* g, hipStream_t st) {
-    static const bool off = getenv("AS_NO_WGRAD") != nullptr;  // ablation: the general kernel
+    static const bool off = AS_DIAG_SET("AS_NO_WGRAD");  // ablation: the general kernel
     if (off) return 0;
     if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->b_kT > 0 || g->act != 0 || g->bias) return 0;
     if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return 0;
@@ -273,18 +277,20 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     k.accumulate = g->accumulate;
     k.c_vec = aligned16(g->C) && g->ldc % 4 == 0 && (g->c_off ? 1 : g->c_batch % 4 == 0);
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
-    static const int abl = getenv("AS_WGRAD_ABL") ? atoi(getenv("AS_WGRAD_ABL")) : 0;
+    #ifdef AS_DIAG
+    static const int abl = AS_DIAG_INT("AS_WGRAD_ABL", 0);
     k.abl = abl;
+#endif
     const int bn = g->N > 128 ? 256 : 128;
     k.tiles_m = as_cdiv(g->M, BM);
     k.tiles_n = as_cdiv(g->N, bn);
     const long tiles = (long)k.tiles_m * k.tiles_n * g->batch;
-    static const bool all_shapes = getenv("AS_WGRAD_ALL") != nullptr;  // tuning aid: also the shapes below
+    static const bool all_shapes = AS_DIAG_SET("AS_WGRAD_ALL");  // tuning aid: also the shapes below
     // too little work to give every CU a 128-row tile over >= 256 frames: the general kernel's 64 x 64 tiles spread it better
     if (!all_shapes && tiles * (g->K / 256) < 256) return 0;
     // split K so that the launch has about `target` workgroups (one per CU and round); cost model in DESIGN.md 5
-    static const int target_env = getenv("AS_WGRAD_TARGET") ? atoi(getenv("AS_WGRAD_TARGET")) : 0;
-    static const int bk = getenv("AS_WGRAD_BK") ? atoi(getenv("AS_WGRAD_BK")) : 32;
+    static const int target_env = AS_DIAG_INT("AS_WGRAD_TARGET", 0);
+    static const int bk = AS_DIAG_INT("AS_WGRAD_BK", 32);
     const int cus = (g->cu_budget > 0 ? g->cu_budget : 256) * (bk == 16 ? 2 : 1);   // slots: two workgroups per CU at BK = 16
     long S = 1;
     const long per = (long)g->batch * g->M * g->N, per_cs = g->colsum ? (long)g->batch * g->M : 0;

@@ -25,6 +25,23 @@ def test_header_symbols_are_exported_and_bound():
     assert L.as_arch() == b"gfx950"
 
 
+def test_product_library_has_no_ablation_switches():
+    """The shipped library reads no AS_* environment variable: ablations, tuning aids and legacy kernels exist only in the
+    -DAS_DIAG flavour (libartspeech_hip_diag.so, `python -m artspeech_amd.build --diag`) that tools/ load on request."""
+    from artspeech_amd import _lib
+    assert _lib.LIB_PATH.endswith("libartspeech_hip.so")
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"AS_[A-Z][A-Z0-9_]{2,}", blob))
+    switches = {n for n in names if not n.startswith((b"AS_ERR_", b"AS_HEAD_", b"AS_WAVE"))}
+    assert not switches, f"environment switches compiled into the product library: {sorted(switches)}"
+    csrc = os.path.join(ROOT, "artspeech_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            for line in open(os.path.join(csrc, f)):
+                if "getenv(" in line and "#define AS_DIAG_" not in line:
+                    assert "ARTSPEECH_" in line, f"{f}: raw getenv outside the AS_DIAG macros: {line.strip()}"
+
+
 def test_layout_is_disjoint_and_counts_parameters():
     from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech, SimpleArtSpeech
     for cls, kw in ((ArtSpeech, {}), (SimpleArtSpeech, {})):

@@ -15,9 +15,9 @@ python3 $GRAFT_REPO_ROOT/tools/step_timeline.py $out/kt/*/*_kernel_trace.csv > $
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/tstep -- python3 $GRAFT_REPO_ROOT/tools/profile_transformer_step.py 32 200 2 > $out/tstep.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/bench_wgrad.py 20 > $out/wgrad_microbench.log 2>&1
-AS_NO_WGRAD=1 python3 tools/bench_wgrad.py 20 >> $out/wgrad_microbench.log 2>&1
+ARTSPEECH_DIAG_LIB=1 AS_NO_WGRAD=1 python3 tools/bench_wgrad.py 20 >> $out/wgrad_microbench.log 2>&1
 python3 tools/bench_heads.py 20 > $out/heads_microbench.log 2>&1
-AS_NO_LIN=1 python3 tools/bench_heads.py 20 >> $out/heads_microbench.log 2>&1
+ARTSPEECH_DIAG_LIB=1 AS_NO_LIN=1 python3 tools/bench_heads.py 20 >> $out/heads_microbench.log 2>&1
 python3 tools/lin_stamps.py > $out/lin_stamps.log 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $out/mfma_peak.log 2>&1
 python3 tools/bench_gru.py 20 > $out/recurrence_microbench.log 2>&1
