@@ -75,13 +75,14 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
 }
 
 struct ModelWs {
-    int64_t tab0, y0, y0d, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
+    int64_t tokflag, tab0, y0, y0d, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
 };
 
 ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
     const int64_t R = B * T, H = d.hidden, V = d.vocab;
     Carve c;
     ModelWs w{};
+    w.tokflag = c.take(64);   // first word (int32): ids outside [0, V) seen by the last as_artspeech_fwd on this workspace
     if (!d.simple) {
         w.tab0 = c.take(V * 6 * H);
         w.y0 = c.take(R * 2 * H);
@@ -489,17 +490,19 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     if (sd) {
         AS_TRY(fork_to(st, sd->side, sd->fork[0]));
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->side));
+        AS_TRY(as_count_bad_tokens(tokens, tok_stride, T, R, V, reinterpret_cast<int*>(ws + w.tokflag), sd->side));
         if (hipEventRecord(sd->join, sd->side) != hipSuccess) {
             as_set_error("as_artspeech_fwd: event record failed");
             return AS_ERR_BAD_ARG;
         }
     } else {
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, st));
+        AS_TRY(as_count_bad_tokens(tokens, tok_stride, T, R, V, reinterpret_cast<int*>(ws + w.tokflag), st));
     }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
         AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));
-        AS_STEP("gru.fwd_l0", st, as_gru_bidir_fwd(ws + w.tab0, tokens, tok_stride, P + L.w_hh[0], P + L.b_hh[0], lengths, B, T, H, ws + w.y0,
+        AS_STEP("gru.fwd_l0", st, as_gru_bidir_fwd_tokens(ws + w.tab0, tokens, tok_stride, V, P + L.w_hh[0], P + L.b_hh[0], lengths, B, T, H, ws + w.y0,
                                 train ? ws + w.g0 : nullptr, st));
         const float* l1_in = ws + w.y0;
         if (pdrop > 0.f) {  // nn.GRU inter-layer dropout: layer 1 sees the dropped layer-0 output
@@ -513,12 +516,12 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     } else if (pdrop > 0.f) {
         // SimpleArtSpeech in training mode (models.py:64,85): Dropout acts on the embedded frame, so every position has its
         // own mask and the token-table fold below does not apply: gather -> counter mask -> Linear + ReLU on all frames
-        AS_TRY(as_gather_rows(P + L.embedding, tokens, tok_stride, T, R, E, ws + w.y0, st));
+        AS_TRY(as_gather_rows(P + L.embedding, tokens, tok_stride, T, R, E, ws + w.y0, st, V));
         AS_TRY(as_dropout(ws + w.y0, ws + w.y0, (long)R * E, pdrop, opts->dropout_seed, st));
         AS_TRY(gemm_nt(ws + w.y0, E, P + L.lin_w, E, ws + w.lin, H, P + L.lin_b, R, H, E, 1, st));
     } else {
         AS_TRY(gemm_nt(P + L.embedding, E, P + L.lin_w, E, ws + w.tab0, H, P + L.lin_b, V, H, E, 1, st));
-        AS_TRY(as_gather_rows(ws + w.tab0, tokens, tok_stride, T, R, H, ws + w.lin, st));
+        AS_TRY(as_gather_rows(ws + w.tab0, tokens, tok_stride, T, R, H, ws + w.lin, st, V));
     }
     if (sd && hipStreamWaitEvent(st, sd->join, 0) != hipSuccess) {  // folded weights ready before head GEMM 1
         as_set_error("as_artspeech_fwd: stream wait failed");

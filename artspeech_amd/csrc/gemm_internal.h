@@ -29,5 +29,12 @@ bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T);   // the [V][3H] t
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,
                             float* part, hipStream_t st);
+// gru.hip: as_gru_bidir_fwd over a token table [V][2][3H] with the ids clamped into [0, V) (memory safety; the composite
+// entry point counts out-of-range ids for the host)
+int as_gru_bidir_fwd_tokens(const float* table, const int64_t* tokens, int64_t tok_stride, int32_t V, const float* w_hh,
+                            const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates,
+                            hipStream_t st);
+// rowops.hip: *count = number of ids outside [0, V) among tokens[b][t], b < rows / T, t < T (one small workgroup)
+int as_count_bad_tokens(const int64_t* tokens, long tok_stride, int T, long rows, int V, int* count, hipStream_t st);
 // rowops.hip: out[i] = sum over chunks (fixed order) of part[chunk][i], i < n
 int as_sum_partials(const float* part, long n, int chunks, float* out, hipStream_t st);

@@ -48,7 +48,7 @@ template <int H, int LPU, bool TRAIN, bool TOK, int AHEAD>
 __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
                                                           long tok_stride, const float* __restrict__ w_hh,
                                                           const float* __restrict__ b_hh, const int* __restrict__ lengths,
-                                                          int T, float* __restrict__ y, float* __restrict__ gates, int nd) {
+                                                          int T, float* __restrict__ y, float* __restrict__ gates, int nd, int V) {
     constexpr int CW = 4 * LPU;   // floats of the reduction index covered by one ds_read_b128 of every lane of a unit
     constexpr int NC = H / CW;    // such chunks; a lane owns 4 floats of each
     constexpr int NT = LPU * H;   // threads
@@ -80,7 +80,10 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
         y[((long)b * T + i / H) * nd * H + dir * H + (i % H)] = 0.f;
     if (tid < H) hbuf[0][tid] = 0.f;
     if (TOK)
-        for (int t = tid; t < len; t += NT) tok_s[t] = (int)tokens[(long)b * tok_stride + t] * (nd * 3 * H * 4);   // bytes
+        for (int t = tid; t < len; t += NT) {   // V > 0: ids clamped into the table (counted for the host by as_artspeech_fwd)
+            const int64_t v = tokens[(long)b * tok_stride + t];
+            tok_s[t] = (int)(V > 0 ? min(max(v, (int64_t)0), (int64_t)V - 1) : v) * (nd * 3 * H * 4);   // bytes
+        }
     __syncthreads();
     if (len <= 0) return;
 
@@ -374,7 +377,9 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
         // the utterance's tokens as table offsets, staged once: a per-step global (or scalar) load of the token put a
         // memory round trip on the step (+0.3 us, measured); an LDS broadcast read one step ahead costs nothing
         int* toff = reinterpret_cast<int*>(tab + (long)V * 3 * H + NT);
-        for (int t = tid; t < len; t += NT) toff[t] = (int)tokens[(long)b * tok_stride + t] * (3 * H);
+        // ids are clamped into [0, V): the table below is read-modify-written every step, so an id from a mismatched
+        // vocabulary must not be able to address LDS outside it (as_artspeech_fwd counts such ids for the host: ws token flag)
+        for (int t = tid; t < len; t += NT) toff[t] = (int)min(max(tokens[(long)b * tok_stride + t], (int64_t)0), (int64_t)V - 1) * (3 * H);
         part_wg = part + (long)b * V * 6 * H + (long)dir * 3 * H;   // + v * 6H + column
         if (len <= 0) {
             for (int i = tid; i < V * 3 * H; i += NT) part_wg[(long)(i / (3 * H)) * 6 * H + i % (3 * H)] = 0.f;
@@ -588,7 +593,8 @@ constexpr int AS_GRU_TOK_LDS_MAX = 128 * 1024;   // token-sum table of the layer
 extern "C" void as_gru_debug_stamps(uint64_t* buf) { g_gru_dbg = (unsigned long long*)buf; }
 
 static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
-                          const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, int nd, void* stream) {
+                          const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, int nd, void* stream,
+                          int V = 0) {
     AS_REQUIRE(gi && w_hh && b_hh && lengths && y, AS_ERR_BAD_ARG, "as_gru_fwd: null pointer");
     AS_REQUIRE(B > 0 && T > 0, AS_ERR_BAD_ARG, "as_gru_fwd: B=%d T=%d", B, T);
     AS_REQUIRE(!tokens || T <= 32768, AS_ERR_UNSUPPORTED, "as_gru_fwd: T=%d > 32768 with a token table", T);
@@ -604,15 +610,15 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
     do {                                                                                                                  \
         if (ahead == 1)                                                                                                   \
             hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 1>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
-                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd);                                   \
+                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V);                                   \
         else                                                                                                              \
             hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
-                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd);                                   \
+                               (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V);                                   \
     } while (0)
 #else
 #define AS_GRU_LAUNCH(HH, TR, TK)                                                                                     \
     hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
-                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd)
+                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V)
 #endif
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
@@ -637,6 +643,13 @@ extern "C" int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t 
                                 const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y,
                                 float* gates, void* stream) {
     return gru_fwd_launch(gi, tokens, tok_stride, w_hh, b_hh, lengths, B, T, H, y, gates, 2, stream);
+}
+
+// internal (gemm_internal.h): the token-table form with the vocabulary size, so that ids are clamped into the table
+int as_gru_bidir_fwd_tokens(const float* table, const int64_t* tokens, int64_t tok_stride, int32_t V, const float* w_hh,
+                            const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates,
+                            hipStream_t st) {
+    return gru_fwd_launch(table, tokens, tok_stride, w_hh, b_hh, lengths, B, T, H, y, gates, 2, st, V);
 }
 
 extern "C" int as_gru_unidir_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int32_t B,

@@ -21,8 +21,9 @@ int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int 
 // dW [C][E] = dtab^T . emb, db [C] = column sums of dtab, demb [V][E] = dtab . W   (dtab [V][C], emb [V][E], W [C][E])
 int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int C, int E, float* dW, float* db, float* demb,
                  hipStream_t st);
+// V > 0: ids are clamped into [0, V) (the table has V rows)
 int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
-                   hipStream_t st);
+                   hipStream_t st, int V = 0);
 int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st);
 int as_relu_mask(const float* g, const float* act, float* dst, long n, hipStream_t st);
 // y = x * mask(seed, i) / (1 - p); x == y allowed (in place); the same (seed, p) regenerates the same mask

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void token_segsum_cols_kernel(const float* __r
     long tb = r / T;
     int tt = (int)(r - tb * T);
     auto next_tok = [&]() {
-        const int v = (int)tokens[tb * tok_stride + tt];
+        const int v = (int)min(max(tokens[tb * tok_stride + tt], (int64_t)0), (int64_t)V - 1);   // never outside the LDS tables
         tt += 4;
         while (tt >= T) { tt -= T; ++tb; }
         return v;
@@ -414,12 +414,32 @@ __global__ __launch_bounds__(1024) void emb_grads_kernel(const float* __restrict
 // ---- out[m][:] = table[token(m)][:] --------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ tokens,
                                                           long tok_stride, int T, long rows, int C,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, int V) {
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= rows) return;
     const long b = m / T, t = m % T;
-    const long v = tokens[b * tok_stride + t];
+    const long v = V > 0 ? min(max(tokens[b * tok_stride + t], (int64_t)0), (int64_t)V - 1) : tokens[b * tok_stride + t];
     for (int c = threadIdx.x & 63; c < C; c += 64) out[m * C + c] = table[v * C + c];
+}
+
+// ---- *count = ids outside [0, V) (nn.Embedding raises for them; the kernels clamp, the host reads this word) ----------
+__global__ __launch_bounds__(1024) void count_bad_tokens_kernel(const int64_t* __restrict__ tokens, long tok_stride, int T, long rows,
+                                                                int V, int* __restrict__ count) {
+    __shared__ int part[16];
+    int bad = 0;
+    for (long m = threadIdx.x; m < rows; m += 1024) {
+        const long b = m / T;
+        const int64_t v = tokens[b * tok_stride + (m - b * T)];
+        bad += (v < 0 || v >= V) ? 1 : 0;
+    }
+    bad = (int)as_wave_sum((float)bad);   // exact below 2^24 ids
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < 16; ++i) s += part[i];
+        *count = s;
+    }
 }
 
 // ---- dpre = dout * out * (1 - out) ----------------------------------------------------------------
@@ -758,9 +778,14 @@ int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int
     return 0;
 }
 int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, int T, long rows, int C, float* out,
-                   hipStream_t st) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, table, tokens, tok_stride, T, rows, C, out);
+                   hipStream_t st, int V) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, table, tokens, tok_stride, T, rows, C, out, V);
     AS_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+int as_count_bad_tokens(const int64_t* tokens, long tok_stride, int T, long rows, int V, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(count_bad_tokens_kernel, dim3(1), dim3(1024), 0, st, tokens, tok_stride, T, rows, V, count);
+    AS_LAUNCH_CHECK("count_bad_tokens");
     return 0;
 }
 int as_sigmoid_bwd(const float* out, const float* dout, float* dpre, long n, hipStream_t st) {

@@ -65,6 +65,19 @@ class TrainStep:
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.dout), _lib.ptr(self.grads), _lib.ptr(self.ws),
                                       C.byref(self.bwd_opts), st), "as_artspeech_bwd")
 
+    def bad_tokens(self):
+        """Number of token ids outside [0, V) in the last batch (device word written by as_artspeech_fwd; the kernels clamp
+        such ids).  Reading it synchronises: call it where the loss is read."""
+        return int(self.ws[:1].view(torch.int32).item())
+
+    def loss_value(self):
+        """float(loss) of the last step; raises like nn.Embedding if that batch held out-of-range token ids."""
+        v = float(self.loss)
+        n = self.bad_tokens()
+        if n:
+            raise IndexError(f"index out of range in self ({n} token ids outside [0, {self.dims.vocab}))")
+        return v
+
     def all_reduce(self):
         """RCCL all-reduce (SUM) of the flat gradient buffer: shard losses are scaled by the GLOBAL valid-frame count, so the
         sum over ranks is the reference's full-batch gradient.  With ``ar_overlap`` the tail of the buffer (trunk Linear +

@@ -94,7 +94,7 @@ class _ArtSpeechFn(torch.autograd.Function):
     as_artspeech_fwd / as_artspeech_bwd (C ABI)."""
 
     @staticmethod
-    def forward(ctx, flat, tokens, lengths_dev, dims, B, T, opts=None):
+    def forward(ctx, flat, tokens, lengths_dev, dims, B, T, opts=None, defer=None):
         L = _lib.lib()
         train = bool(ctx.needs_input_grad[0])  # (grad mode is always off inside Function.forward)
         out = torch.empty((B, T, dims.n_art, 2, dims.n_samp), dtype=torch.float32, device=flat.device)
@@ -105,6 +105,12 @@ class _ArtSpeechFn(torch.autograd.Function):
         _lib.check(L.as_artspeech_fwd(C.byref(dims), _lib.ptr(flat), _lib.ptr(tokens), tokens.stride(0),
                                       _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(ws), int(train),
                                       C.byref(opts) if opts is not None else None, _lib.stream_ptr()), "as_artspeech_fwd")
+        # nn.Embedding raises for ids outside [0, V) (reference models.py:135); the kernels clamp them (memory safety) and
+        # count them in the first word of the workspace -- read here, where the drop-in path may synchronise
+        if defer is None:
+            _raise_if_bad_tokens(ws, dims.vocab)
+        else:
+            defer.append(ws)   # a loop that synchronises anyway (loss.item()) calls model.check_tokens() there
         if train:
             ctx.save_for_backward(flat, tokens, lengths_dev, out, ws)
             ctx.meta = (dims, B, T, opts)
@@ -121,7 +127,13 @@ class _ArtSpeechFn(torch.autograd.Function):
                                       _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(dout), _lib.ptr(grads),
                                       _lib.ptr(ws), C.byref(opts) if opts is not None else None, _lib.stream_ptr()),
                    "as_artspeech_bwd")
-        return grads, None, None, None, None, None, None
+        return grads, None, None, None, None, None, None, None
+
+
+def _raise_if_bad_tokens(ws, vocab):
+    n_bad = int(ws[:1].view(torch.int32).item())
+    if n_bad:
+        raise IndexError(f"index out of range in self ({n_bad} token ids outside [0, {vocab}))")
 
 
 class _FlatModule(nn.Module):
@@ -137,6 +149,23 @@ class _FlatModule(nn.Module):
         for k, (off, shape) in self._views.items():
             flat[off:off + _numel(shape)] = init_sd[k].reshape(-1).to(torch.float32)
         self.flat = nn.Parameter(flat)
+
+    # Token-id check (nn.Embedding raises IndexError, reference models.py:135).  Default: forward() reads the device-side
+    # count right after its launch (one synchronisation, the reference's behaviour).  A training loop that synchronises
+    # once per step anyway sets ``defer_token_check = True`` and calls ``check_tokens()`` next to its ``loss.item()``.
+    defer_token_check = False
+
+    def _defer_list(self):
+        if not self.defer_token_check:
+            return None
+        if not hasattr(self, "_pending_ws"):
+            self._pending_ws = []
+        return self._pending_ws
+
+    def check_tokens(self):
+        pending, self._pending_ws = getattr(self, "_pending_ws", []), []
+        for ws in pending:
+            _raise_if_bad_tokens(ws, self.dims.vocab)
 
     def named_views(self):
         """state_dict key -> view of the flat parameter (shares storage)."""
@@ -218,7 +247,7 @@ class ArtSpeech(_FlatModule):
             # nn.GRU(dropout=p): inter-layer dropout in training mode.  The seed is drawn from torch's CPU
             # generator, so torch.manual_seed() controls it (statistical parity with the reference's mask).
             opts = _lib.Opts(self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item()))
-        return _ArtSpeechFn.apply(self.flat, x, lengths_dev, self.dims, x.shape[0], T, opts)
+        return _ArtSpeechFn.apply(self.flat, x, lengths_dev, self.dims, x.shape[0], T, opts, self._defer_list())
 
 
 class SimpleArtSpeech(_FlatModule):
@@ -242,4 +271,4 @@ class SimpleArtSpeech(_FlatModule):
             # nn.Dropout on the embedded frames (reference models.py:64,85): per-position counter mask, seed drawn from
             # torch's CPU generator like the GRU model's inter-layer dropout
             opts = _lib.Opts(self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item()))
-        return _ArtSpeechFn.apply(self.flat, x, None, self.dims, x.shape[0], x.shape[1], opts)
+        return _ArtSpeechFn.apply(self.flat, x, None, self.dims, x.shape[0], x.shape[1], opts, self._defer_list())

@@ -72,6 +72,12 @@ int as_artspeech_layout(const as_dims* dims, as_layout* out);
 /* ------------------------------------------------------------------------------------------------
  * Workspace: one caller-allocated float buffer holds every intermediate and saved activation of a
  * training step for a (B, T) batch.  as_artspeech_workspace_floats() returns its size in floats.
+ *
+ * Token ids: the reference's nn.Embedding (models.py:135) raises IndexError for an id outside [0, V).  The kernels
+ * never sync, so instead every kernel that indexes a table by token id clamps the id into the table (no out-of-range
+ * access whatever the input), and as_artspeech_fwd leaves the NUMBER of out-of-range ids of its batch in the first
+ * 32-bit word of the workspace (int32): the host raises when it reads a non-zero count (the drop-in modules read it
+ * after every forward; the training engine whenever it reads the loss).
  * ---------------------------------------------------------------------------------------------- */
 int64_t as_artspeech_workspace_floats(const as_dims* dims, int32_t B, int32_t T);
 

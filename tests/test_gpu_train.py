@@ -382,3 +382,53 @@ def test_overlapped_gradient_all_reduce_equals_single_all_reduce(dev):
     cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0 and res.stdout.count("ok = True") == 2, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("bad", ["V", "negative"])
+def test_out_of_range_token_ids_raise_like_nn_embedding(dev, bad):
+    """nn.Embedding raises IndexError for an id outside [0, V) (reference models.py:135).  Here the kernels clamp such ids
+    into their tables (the layer-0 backward keeps per-token sums in LDS: an id >= V must never address memory outside them)
+    and as_artspeech_fwd counts them for the host: the drop-in forward raises at once, the deferred form and the training
+    engine raise where they synchronise, and a whole step with a bad id runs to completion without touching other memory."""
+    from artspeech_amd import engine
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech, SimpleArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(0)
+    V, A, B, T = 45, 3, 4, 64          # V <= T: the token-sum variant of the layer-0 backward recurrence
+    lengths = torch.tensor([64, 50, 33, 7])
+    x = torch.randint(1, V, (B, T))
+    tgt = torch.rand(B, T, A, 2, 50)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    x_bad = x.clone()
+    x_bad[1, 5] = V if bad == "V" else -3
+    x_bad[0, 63] = V + 100000 if bad == "V" else -(1 << 40)
+    for cls in (ArtSpeech, SimpleArtSpeech):
+        model = cls(V, A).to(dev)
+        out = model(x.to(dev), lengths)          # valid ids pass
+        assert torch.isfinite(out).all()
+        with pytest.raises(IndexError, match="out of range"):
+            model(x_bad.to(dev), lengths)
+        # deferred: forward + loss + backward run (clamped ids, no fault), the check raises afterwards
+        model.defer_token_check = True
+        out = model(x_bad.to(dev), lengths)
+        loss = masked_euclidean_loss(out, tgt.to(dev), lengths.numpy())
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(model.flat.grad).all()
+        with pytest.raises(IndexError, match="2 token ids outside"):
+            model.check_tokens()
+        model.check_tokens()                      # the pending list is consumed
+    # training engine: the count is read with the loss
+    model = ArtSpeech(V, A).to(dev)
+    step = engine.TrainStep(model, B, T)
+    ld = lengths.to(torch.int32).to(dev)
+    scale = 1.0 / (float(lengths.sum()) * A * 50)
+    step.step(x.to(dev), ld, tgt.to(dev), scale)
+    assert np.isfinite(step.loss_value())
+    step.step(x_bad.to(dev), ld, tgt.to(dev), scale)
+    with pytest.raises(IndexError, match="out of range"):
+        step.loss_value()
+    step.step(x.to(dev), ld, tgt.to(dev), scale)   # the count is per batch, not sticky
+    assert np.isfinite(step.loss_value())

@@ -69,6 +69,9 @@ def run_epoch(phase, epoch, model, dataloader, optimizer, criterion, fn_metrics=
     metrics_values = {name: [] for name in fn_metrics}
     # reduction "none" (the training configuration): criterion + mask + mean collapse into one kernel
     fused = isinstance(criterion, EuclideanDistance) and getattr(torch, criterion.reduction_name, None) is None
+    deferred = hasattr(model, "check_tokens")   # token-id check next to the loop's own loss.item() instead of a sync per forward
+    if deferred:
+        model.defer_token_check = True
     for _, sentence, targets, lengths, _, _, _, _ in dataloader:
         n_valid_global = int(lengths.sum())
         if world > 1:  # every rank sees the same global batch (same sampler seed) and keeps its shard
@@ -98,6 +101,8 @@ def run_epoch(phase, epoch, model, dataloader, optimizer, criterion, fn_metrics=
             for name, fn_metric in fn_metrics.items():
                 metrics_values[name].append(fn_metric(outputs, targets, lengths).item())
             losses.append(step_loss.item())
+            if deferred:
+                model.check_tokens()   # IndexError like nn.Embedding (reference models.py:135) for ids outside the vocabulary
     info = {"loss": float(np.mean(losses))}
     info.update({name: float(np.mean(vals)) for name, vals in metrics_values.items()})
     return info
