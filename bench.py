@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the phoneme_to_articulation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--per-gpu-batch b]
 
 With --gpus N > 1 and no torchrun environment, bench.py starts the N ranks itself as CHILD processes
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`)
@@ -16,6 +16,10 @@ timed region.  V=45, E=64, H=128, A=11 articulators x 50 points, T=200.
   strong scaling (configs[2] "same as above, batch-sharded"): ONE global batch of 32 utterances dealt
   round-robin over the ranks (B=32/N per GPU), loss scaled by the global valid-frame count.
 For N > 1 both are measured back to back and both are in the line (`scaling_runs`).
+
+--per-gpu-batch b (N = 1 only): the same step on b utterances instead of 32 -- what ONE rank of an N = 32/b strong-scaling
+run computes.  The default N = 1 run also measures b = 16, 8, 4 after the headline (`strong_scaling_bound`): the ceiling
+T(32) / [T(32/N) + all-reduce] that configs[2] read as ONE global batch of 32 can reach, beside the weak reading.
 
 Prints ONE JSON line on rank 0 (metric: articulator-frames/sec, fwd+bwd).  At N = 1 the line also
 carries the driver-timed numbers of configs[3] (`transformer_c4`) and configs[4] on one GPU
@@ -92,7 +96,7 @@ GRU_BWD_TOK_KERNEL = "gru_bwd_row_kernel<128, true, 2>"
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
     runs, gfx950 correction applied: tools/collect_profiles.py), newest round first, or None."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if not os.path.exists(path):
             continue
@@ -102,6 +106,21 @@ def pmc_traffic(kernel):
             if kernel in name:
                 return rec["hbm_bytes_per_launch"]
     return None
+
+
+def measured_copy_gbs(dev, mib=1024, reps=10):
+    """Streaming copy rate of THIS box (read + write bytes over time, a 1 GiB fp32 tensor copied `reps` times): the
+    measured denominator SURVEY 8(d) asks for beside the 8 TB/s spec figure."""
+    src = torch.empty(mib << 18, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
 def host_cores():
@@ -192,6 +211,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="which run is the headline `value` (N > 1 measures both)")
+    ap.add_argument("--per-gpu-batch", type=int, default=B,
+                    help="N = 1 only: utterances in the batch (default 32); b < 32 = one rank's share of a strong-scaling run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] measurements (N = 1)")
@@ -206,6 +227,10 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if B % world:
         raise SystemExit(f"--gpus {world} does not divide the global batch of {B} utterances")
+    if args.per_gpu_batch != B and world > 1:
+        raise SystemExit("--per-gpu-batch is a single-GPU measurement (no process group)")
+    if args.per_gpu_batch < 1:
+        raise SystemExit("--per-gpu-batch must be positive")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     backend = os.environ.get("ARTSPEECH_DIST_BACKEND", "nccl")
     if backend != "nccl":
@@ -237,11 +262,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(mode):
+    def measure(mode, b_one=None):
         """W warm-up + K timed steps of `mode`; returns (elapsed max over ranks, loss, TrainStep, inputs)."""
         model.flat.data.copy_(flat0)  # every run starts from the same parameters
-        if mode == "weak":     # each rank holds its own batch of B utterances
-            tokens, targets, lengths = make_batch(B, seed=1 + rank)
+        if mode == "weak":     # each rank holds its own batch of B utterances (b_one: --per-gpu-batch, N = 1)
+            tokens, targets, lengths = make_batch(b_one or B, seed=1 + rank)
             n_valid_global = int(lengths.sum()) * world
         else:                  # one global batch of B utterances, dealt round-robin (artspeech_amd/distributed.py)
             tokens, targets, lengths = make_batch(B, seed=1)
@@ -278,7 +303,7 @@ def main():
     runs = {}
     head_step = head_inputs = None
     for m in modes:
-        rec, st, inp = measure(m)
+        rec, st, inp = measure(m, args.per_gpu_batch if world == 1 else None)
         runs[m] = rec
         if m == args.scaling:
             head_step, head_inputs = st, inp
@@ -318,10 +343,20 @@ def main():
                 return {"kernel": f"{kernel} ({phase})", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel),
                         "us_per_launch": round(us, 2), "algorithmic_bytes_per_launch": nbytes[phase]}
-            roofline = entry(GRU_BWD_KERNEL, "gru.bwd_l1")
+            # headline entry = the LONGER of the two backward-recurrence launches (layer 0 runs the token-sum variant)
+            l1 = entry(GRU_BWD_KERNEL, "gru.bwd_l1")
+            l0 = entry(GRU_BWD_TOK_KERNEL, "gru.bwd_l0") if ("gru.bwd_l0" in kernels and kernels["gru.bwd_l0"]["launches_per_step"] == 1) else None
+            if l0 is not None and l0["us_per_launch"] > l1["us_per_launch"]:
+                roofline, other, other_key = l0, l1, "layer1_variant"
+            else:
+                roofline, other, other_key = l1, l0, "layer0_variant"
             roofline["note"] = "dependent-step (latency) bound: 200 sequential recurrent steps per launch"
-            if "gru.bwd_l0" in kernels and kernels["gru.bwd_l0"]["launches_per_step"] == 1:
-                roofline["layer0_variant"] = entry(GRU_BWD_TOK_KERNEL, "gru.bwd_l0")
+            roofline["traffic_source"] = "committed rocprofv3 --pmc passes of the same command (profiles/rNN_pmc_traffic.json), not this run"
+            copy_gbs = measured_copy_gbs(dev)
+            roofline["peak_measured_copy"] = copy_gbs   # the box's own streaming-copy rate beside the 8 TB/s spec
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5)
+            if other is not None:
+                roofline[other_key] = other
         else:
             roofline = {}
         # (2) the matrix side: every GEMM phase grouped by the kernel that runs it; FLOPs / time / fp32-MFMA peak.
@@ -353,6 +388,27 @@ def main():
 
     if rank == 0:
         extras = {}
+        if world == 1 and not args.no_extras and args.per_gpu_batch == B:
+            # what one rank of a strong-scaling run of configs[2] computes: the same step on 32/N utterances
+            t32 = ms_per_step
+            sweep = {}
+            for n_ranks in (2, 4, 8):
+                rec, st, inp = measure("weak", B // n_ranks)
+                del st, inp
+                tb = rec["ms_per_step"]
+                # gradient all-reduce of 7.46 MB, NOT measured here (one GPU): a ring over xGMI moves 2(N-1)/N of the
+                # buffer per rank; assumed 100 GB/s effective + 30 us latency; the two-piece schedule hides 74 % of the
+                # buffer beside the GRU backward, so the exposed time lies between the two figures
+                ar_ms = (2.0 * (n_ranks - 1) / n_ranks * 7.46e6 / 100e9 + 30e-6) * 1e3
+                sweep[f"N={n_ranks}"] = {"per_gpu_batch": B // n_ranks, "ms_per_step_one_rank": tb,
+                                         "speedup_ceiling_allreduce_hidden": round(t32 / tb, 2),
+                                         "speedup_allreduce_exposed": round(t32 / (tb + ar_ms), 2),
+                                         "assumed_allreduce_ms": round(ar_ms, 3)}
+            extras["strong_scaling_bound"] = {
+                "note": "configs[2] read as ONE global batch of 32 dealt over N ranks: T(32) / [T(32/N) + all-reduce], T measured "
+                        "on this GPU, all-reduce ASSUMED (100 GB/s effective ring + 30 us); the recurrences' 800 dependent "
+                        "steps do not shrink with the batch, so >= 6x at N = 8 is only reachable under weak scaling",
+                "ms_per_step_B32": t32, "by_ranks": sweep}
         if world == 1 and not args.no_extras:
             # configs[3] / configs[4] on this GPU, timed by the same command (their own workloads, not `value`)
             torch.cuda.empty_cache()
@@ -380,7 +436,8 @@ def main():
                                    "masked Euclidean loss + bwd + flat grad all-reduce + Adam",
                        "global_batch": head["global_batch"], "seq_len": T, "parallelism": f"dp{world}"},
             "loss": head["loss"],
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            # ranks that exchanged gradients over RCCL (0 in a gloo rehearsal, where no RCCL communicator exists)
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "rehearsal_shared_gpu": bool(world > 1 and backend != "nccl"),
             "scaling_runs": runs,
