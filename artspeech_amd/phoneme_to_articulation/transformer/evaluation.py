@@ -31,9 +31,13 @@ def run_transformer_test(epoch, model, dataloader, criterion, outputs_dir, artic
         idx = torch.tensor(keep, device=device)
         outputs, targets = outputs[idx], targets[idx]
         reference_arrays = reference_arrays[keep]
-        lengths_k = lengths[keep]
-        # the kept utterances stay sorted by length; the masked loss only needs lengths <= T
-        loss = masked_euclidean_loss(outputs.contiguous(), targets.contiguous(), lengths_k)
-        acc.add(loss.item(), outputs, targets, lengths_k, [sentences_ids[i] for i in keep], [sentence_frames[i] for i in keep],
-                [phonemes[i] for i in keep], reference_arrays)
+        # the loss sees the kept utterances with their own lengths (reference :81-86: the padding mask is filtered) ...
+        loss = masked_euclidean_loss(outputs.contiguous(), targets.contiguous(), lengths[keep])
+        # ... but the metrics and the files do not: the reference zips the KEPT outputs with the UNFILTERED lengths, sentence
+        # ids, frames and phonemes (:96, :146-168), so kept utterance j is measured over lengths[j] frames and reported under
+        # sentences_ids[j] of the whole batch.  Kept as it is (pinned by tests/golden/transformer_loops.npz): lengths are
+        # sorted in decreasing order, so lengths[j] never exceeds the padded length of a kept prediction.
+        n = len(keep)
+        acc.add(loss.item(), outputs, targets, lengths[:n], list(sentences_ids[:n]), list(sentence_frames[:n]), list(phonemes[:n]),
+                reference_arrays)
     return acc.info(dataloader.dataset.dataset_config)

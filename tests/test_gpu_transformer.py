@@ -1,10 +1,12 @@
 """GPU parity of the transformer variant (inference) against fixtures produced by the reference itself and
 against the numpy oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_wg
+from conftest import assert_grad_close, load_golden, split_wg
 from oracle import transformer_oracle as TO
 
 pytestmark = pytest.mark.gpu
@@ -544,3 +546,135 @@ def test_full_width_model_matches_reference_fixture(dev):
         f = 2.0 if i == 3 else 1.5
         assert got_n[i] <= f * float(g["self_norm_q"][i]), (q[i], got_n[i], float(g["self_norm_q"][i]))
         assert got_s[i] <= f * float(g["self_slice_q"][i]), (q[i], got_s[i], float(g["self_slice_q"][i]))
+
+
+class _CapturedLoader:
+    def __init__(self, batches, dataset_config):
+        import types
+        self.batches = batches
+        self.dataset = types.SimpleNamespace(dataset_config=dataset_config)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _perturb_by_key(i, k, v):
+    """tests/golden/make_golden.py::perturb_by_key (the fixture model = seeded init + this, by sorted state_dict key)."""
+    if k == "pos_encoding.pe":
+        return v
+    n = v.numel()
+    out = v + (0.02 * torch.cos(0.37 * torch.arange(n, dtype=torch.float64) + i)).to(v.dtype).view(v.shape)
+    return out * 0.1 if k == "tgt_embedding.1.weight" else out
+
+
+def test_transformer_loops_match_reference_fixture(dev, tmp_path, monkeypatch, capsys):
+    """tests/golden/transformer_loops.npz holds what the REFERENCE's transformer harnesses produced on a captured 6-utterance
+    loader: run_epoch(TRAIN) with SGD and run_epoch(VALID) with p2cp_mean (train_phoneme_to_articulation_transformer.py:49-149),
+    and run_transformer_test (transformer/evaluation.py:19-191) with ONE utterance whose source is fully masked, so that the
+    prediction is NaN and the filter of :69-86 runs.  The drop-in loops must reproduce the info dicts, the parameter update
+    of the epoch, the skipped sentence, the directories written (the reference reports kept utterance j under the j-th id of
+    the unfiltered batch) and the tract-variable tables."""
+    import csv
+    import train_phoneme_to_articulation_transformer as tr
+    from conftest import load_golden
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.metrics import P2CPDistance
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance
+    from artspeech_amd.phoneme_to_articulation.transformer import models as tmodels
+    from artspeech_amd.phoneme_to_articulation.transformer.evaluation import run_transformer_test
+    from artspeech_amd.settings import DATASET_CONFIG, TRAIN, VALID
+    g = load_golden("transformer_loops")
+    V, A, d, heads, L, nf = (int(v) for v in g["cfg"])
+    arts = [str(a) for a in g["articulators"]]
+    # the fixture model has every dropout probability at 0 (the encoder's library-default 0.1 is a random mask)
+    monkeypatch.setattr(tmodels, "ENC_DROPOUT", 0.0)
+    torch.manual_seed(33)
+    model = tmodels.ArtSpeechTransformer(V, A, embed_dim=d, num_heads=heads, num_layers=L, num_feat=nf)
+    sd = model.state_dict()
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - float(g["init_abs_sum"])) < 1e-6 * float(g["init_abs_sum"])
+    model.load_state_dict({k: _perturb_by_key(i, k, v) for i, (k, v) in enumerate(sorted(sd.items()))})
+    w0 = {k: v.detach().clone().double() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    items = []
+    for i in range(len(g["lens"])):
+        items.append((str(g[f"in{i}_id"]), torch.from_numpy(g[f"in{i}_tokens"]), torch.from_numpy(g[f"in{i}_targets"]),
+                      [str(p) for p in g[f"in{i}_phonemes"]], torch.from_numpy(g[f"in{i}_refs"]), torch.tensor([], dtype=torch.int),
+                      [str(f) for f in g[f"in{i}_frames"]], torch.from_numpy(g[f"in{i}_voicing"])))
+    cfg = DATASET_CONFIG["artspeech2"]
+    batches = [pad_sequence_transformer_collate_fn(items[:3]), pad_sequence_transformer_collate_fn(items[3:])]
+    loader = _CapturedLoader(batches, cfg)
+    crit = EuclideanDistance("none")
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    info = tr.run_epoch(TRAIN, 1, model, loader, opt, crit, device=dev)
+    assert set(info) == {"loss"}
+    assert abs(info["loss"] - float(g["train_loss"])) < 2e-6, (info["loss"], float(g["train_loss"]))
+    # what the two SGD steps changed: per tensor, norm and a strided slice of w1 - w0 (fp32 parameters: an ulp of |w| rides on
+    # every difference besides the update itself)
+    sd1 = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    keys = [str(k) for k in g["upd_keys"]]
+    assert keys == sorted(sd1)
+    for i, k in enumerate(keys):
+        dlt = (sd1[k] - w0[k]).flatten()
+        wmax = max(1.0, float(w0[k].abs().max()))
+        assert abs(float(dlt.norm()) - float(g["upd_norm"][i])) <= 1e-3 * float(g["upd_norm"][i]) + 2.5e-7 * wmax * dlt.numel() ** 0.5, k
+        sl = dlt[::max(1, dlt.numel() // 33)][:33].numpy()
+        assert_grad_close(sl, g["upd_slices"][i, :len(sl)].astype(np.float64), f"transformer_loops: SGD delta of {k}",
+                          rtol=1e-3, atol_frac=1e-4, atol_abs=2.5e-7 * wmax + 1e-4 * float(g["upd_max"][i]))
+    vinfo = tr.run_epoch(VALID, 1, model, loader, opt, crit, fn_metrics={"p2cp_mean": P2CPDistance(cfg)}, device=dev)
+    assert set(vinfo) == {"loss", "p2cp_mean"}
+    assert abs(vinfo["loss"] - float(g["valid_loss"])) < 2e-6
+    assert abs(vinfo["p2cp_mean"] - float(g["valid_p2cp_mean"])) / float(g["valid_p2cp_mean"]) < 2e-3
+    # ---- test loop with the NaN utterance
+    tb = [list(b) for b in batches]
+    nb, nr = int(g["nan_batch"]), int(g["nan_row"])
+    tb[nb][8] = tb[nb][8].clone()
+    tb[nb][8][nr] = float("-inf")
+    test_loader = _CapturedLoader([tuple(b) for b in tb], cfg)
+    capsys.readouterr()
+    res = run_transformer_test(7, model, test_loader, crit, str(tmp_path), arts, device=dev, regularize_out=False)
+    printed = capsys.readouterr().out
+    assert "Invalid outputs produced for sentences:" in printed
+    skipped = [ln.strip() for ln in printed.split("Invalid outputs produced for sentences:")[1].strip().splitlines() if ln.strip()]
+    assert skipped == [str(s) for s in g["skipped"]] == ["sent2"]
+    assert list(res) == ["loss"] + arts
+    assert abs(res["loss"] - float(g["test_loss"])) < 2e-6, (res["loss"], float(g["test_loss"]))
+    names = [str(n) for n in g["test_metric_names"]]
+    # free-running generate() feeds its own 1e-6 differences back for up to 17 frames; correlations of 4..17 samples
+    tol = {"x_corr": ("abs", 2e-4), "y_corr": ("abs", 2e-4), "p2cp": ("rel", 2e-3), "p2cp_mm": ("rel", 2e-3), "med": ("rel", 2e-5),
+           "med_mm": ("rel", 2e-5)}
+    for i, a in enumerate(arts):
+        assert list(res[a]) == names
+        for j, n in enumerate(names):
+            want, got = float(g["test_metrics"][i, j]), res[a][n]
+            err = abs(got - want) / (abs(want) if tol[n][0] == "rel" else 1.0)
+            assert err < tol[n][1], (a, n, got, want)
+    # directories: the kept utterances of the NaN batch are reported under the first ids of the unfiltered batch
+    dirs = sorted(os.listdir(os.path.join(str(tmp_path), "7")))
+    assert dirs == [str(s) for s in g["sentence_dirs"]]
+    first = str(g["first_dir"])
+    sdir = os.path.join(str(tmp_path), "7", first)
+    assert sorted(os.listdir(os.path.join(sdir, "contours"))) == [str(f) for f in g["contour_files"]]
+    with open(os.path.join(sdir, "phonemes.csv")) as f:
+        assert [list(r) for r in csv.reader(f)] == [[str(c) for c in r] for r in g["phonemes_csv"]]
+    assert np.abs(np.load(os.path.join(sdir, "contours", f"{str(g['first_frame'])}_tongue.npy")) - g["pred_tongue_first"]).max() < 2e-5
+    num = [str(c) for c in g["tv_numeric_columns"]]
+    for sd_ in dirs:
+        with open(os.path.join(str(tmp_path), "7", sd_, "tract_variables.csv")) as f:
+            rows = list(csv.reader(f))
+        cols = rows[0]
+        assert cols == [str(c) for c in g["tv_columns"]]
+        assert [r[cols.index("frame")] for r in rows[1:]] == [str(v) for v in g[f"tv_{sd_}_frames"]]
+        assert [r[cols.index("phoneme")] for r in rows[1:]] == [str(v) for v in g[f"tv_{sd_}_phonemes"]]
+        got = np.array([[float(r[cols.index(c)]) for c in num] for r in rows[1:]])
+        want = g[f"tv_{sd_}_values"]
+        tcols = [j for j, c in enumerate(num) if "_target_poc_" in c]
+        assert np.array_equal(got[:, tcols], want[:, tcols]), sd_      # targets are inputs: the same closest pairs, bit for bit
+        dcols = [j for j, c in enumerate(num) if c.endswith("_target")]
+        assert (np.abs(got[:, dcols] - want[:, dcols]) <= 2e-7 / np.maximum(want[:, dcols], 1e-4) + 1e-7).all(), sd_
+        vcols = [j for j, c in enumerate(num) if c.endswith("_pred")]
+        assert (np.abs(got[:, vcols] - want[:, vcols]) <= 2e-7 / np.maximum(want[:, vcols], 1e-4) + 3e-5).all(), sd_
+        pcols = [j for j, c in enumerate(num) if "_pred_poc_" in c]
+        assert (np.abs(got[:, pcols] - want[:, pcols]) < 3e-5).mean() > 0.95, sd_

@@ -303,3 +303,62 @@ def test_oracle_reproduces_the_reference_training_and_test_loops():
     for a in range(A):
         for n in ("x_corr", "y_corr", "med"):
             assert abs(np.mean(per_art[n][a]) - g["test_metrics"][a, names.index(n)]) < 2e-6, (a, n)
+
+
+def test_transformer_oracle_reproduces_the_reference_loops_incl_nan_filter():
+    """tests/golden/transformer_loops.npz (the reference's run_epoch(VALID) and run_transformer_test at the fixture's
+    initial weights): the fp64 oracle, stepped by hand, gives the same VALID loss, marks the same utterance NaN when its
+    source is fully masked, and -- with the reference's pairing of KEPT predictions with the UNFILTERED lengths
+    (transformer/evaluation.py:96) -- the same test loss and mean Euclidean distances."""
+    import torch
+    from oracle import transformer_oracle as TO
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    g = load_golden("transformer_loops")
+    cfg = tuple(int(v) for v in g["cfg"])
+    V, A, d, heads, L, nf = cfg
+    torch.manual_seed(33)                       # seeded init of the drop-in class == the reference's (tested contract) ...
+    sd = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=heads, num_layers=L, num_feat=nf).state_dict()
+    w = {}
+    for i, (k, v) in enumerate(sorted(sd.items())):   # ... + make_golden.py::perturb_by_key
+        if k != "pos_encoding.pe":
+            v = v + (0.02 * torch.cos(0.37 * torch.arange(v.numel(), dtype=torch.float64) + i)).to(v.dtype).view(v.shape)
+            v = v * 0.1 if k == "tgt_embedding.1.weight" else v
+        w[k] = v.numpy()
+    items = []
+    for i in range(len(g["lens"])):
+        items.append((str(g[f"in{i}_id"]), torch.from_numpy(g[f"in{i}_tokens"]), torch.from_numpy(g[f"in{i}_targets"]),
+                      [str(p) for p in g[f"in{i}_phonemes"]], torch.from_numpy(g[f"in{i}_refs"]), torch.tensor([], dtype=torch.int),
+                      [str(f) for f in g[f"in{i}_frames"]], torch.from_numpy(g[f"in{i}_voicing"])))
+    batches = [pad_sequence_transformer_collate_fn(items[:3]), pad_sequence_transformer_collate_fn(items[3:])]
+    losses = []
+    for c in batches:   # run_epoch(VALID): eval + no grad -> the encoder's nested-tensor path (zeros at padded sources)
+        tokens, targets, lengths = c[1].numpy(), c[2].numpy(), c[3].numpy()
+        bs, T = tokens.shape
+        shifted = np.concatenate([np.zeros((bs, 1, A, nf)), targets[:, 1:].reshape(bs, T - 1, A, nf)], 1)
+        out = TO.forward(w, cfg, tokens, shifted, c[10].numpy(), c[11].numpy(), c[8].numpy(), c[9].numpy(), grad_mode=False)
+        losses.append(O.masked_euclid_loss(out, targets, lengths)[0])
+    assert abs(np.mean(losses) - float(g["valid0_loss"])) < 2e-6
+    # run_transformer_test with the NaN utterance
+    nb, nr = int(g["nan_batch"]), int(g["nan_row"])
+    losses, med = [], [[] for _ in range(A)]
+    for ib, c in enumerate(batches):
+        tokens, targets, lengths, kpm = c[1].numpy(), c[2].numpy(), c[3].numpy(), c[8].numpy().copy()
+        if ib == nb:
+            kpm[nr] = -np.inf
+        with np.errstate(invalid="ignore"):
+            gen = TO.generate(w, cfg, tokens, kpm)
+        nan = np.isnan(gen).reshape(gen.shape[0], -1).any(1)
+        assert list(np.nonzero(nan)[0]) == ([nr] if ib == nb else [])
+        keep = np.nonzero(~nan)[0]
+        gen, tgt = gen[keep], targets[keep]
+        losses.append(O.masked_euclid_loss(gen, tgt, lengths[keep])[0])        # the loss: filtered padding mask (:81-86)
+        for j in range(len(keep)):                                             # the metrics: unfiltered lengths (:96)
+            l = int(lengths[j])
+            dist = O.euclidean_distance(gen[j:j + 1, :l], tgt[j:j + 1, :l])    # (1, l, A, N)
+            for a in range(A):
+                med[a].append(dist[0, :, a].mean(-1).mean())
+    assert abs(np.mean(losses) - float(g["test0_loss"])) < 5e-6
+    names = [str(n) for n in g["test_metric_names"]]
+    want = g["test0_metrics"][:, names.index("med")]
+    assert np.abs(np.array([np.mean(m) for m in med]) - want).max() < 5e-6
