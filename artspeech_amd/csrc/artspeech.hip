@@ -584,7 +584,24 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus));
     AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
     AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
-    AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
+    {
+        // input gradient of GRU layer 1: [R][6H] . [6H][2H].  (diagnostic build, AS_DX1_LIN: the LDS-DMA kernel of the head
+        // layers on 32-row x 256-column tiles instead of the general kernel's 64 x 64 tiles + in-kernel split-K)
+        static const bool dx1_lin = AS_DIAG_SET("AS_DX1_LIN");
+        int took = 0;
+        if (dx1_lin && 2 * H == 256) {
+            as_lin l{};
+            l.A = ws + w.dgi1; l.lda = 6 * H;
+            l.B = P + L.w_ih[1]; l.ldb = 2 * H; l.b_kc = 0;
+            l.C = ws + w.dy0; l.ldc = 2 * H;
+            l.M = R; l.N = 2 * H; l.K = 6 * H; l.batch = 1;
+            AS_PROF("grub.dx1", st);
+            took = as_lin_try(&l, st);
+            AS_REQUIRE(took >= 0, took, "grub.dx1: launch failed");
+        }
+        if (!took)
+            AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
+    }
     if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence

@@ -31,6 +31,9 @@ namespace {
 constexpr int BM = 128, NT = 512, NBUF = 3;
 constexpr int KALIGN = 32;   // reduction chunks are multiples of both k-tile depths
 
+// source of the shifted B operand's out-of-sequence rows (b_kT > 0): one row of zeros the DMA can read
+__device__ __attribute__((aligned(16))) float g_zero_row[256];
+
 struct WgradK {
     const float* A; const float* B; float* C;
     int M, N, K;
@@ -109,13 +112,35 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
     const float* b_src = B + (long)(kbeg + wave * PB * RB + (RB == 2 ? lh : 0)) * g.ldb + b_col;  // + j * RB rows
     float* const a_dst = smem + wave * PA * 256;             // + j * 256, + slot * TILE
     float* const b_dst = smem + BK * BM + wave * PB * 256;
+    // Time-shifted B (b_kT > 0; dW_hh = dgh^T . h_prev, models.py:111 through autograd): reduction row k is frame t = k % kT
+    // of its sequence and reads row k + shift, or zeros when t + shift leaves [0, kT) (h_{-1} = 0).  The DMA takes per-lane
+    // source addresses, so such a row simply comes from g_zero_row.  Each piece keeps its frame index and advances it by BK
+    // per k-tile (no division in the loop).
+    const int kshift = g.b_kT > 0 ? g.b_kshift + bz * g.b_kshift_batch : 0;
+    int b_t[PB];
+    if (g.b_kT > 0) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) b_t[j] = (kbeg + wave * PB * RB + (RB == 2 ? lh : 0) + j * RB) % g.b_kT;
+    }
+    const float* const zero_src = g_zero_row + (RB == 1 ? lane * 4 : l31 * 4);
     auto issue = [&](int kt) {  // the PA + PB DMA pieces of this wave for k-tile kt
         float* base = smem + (kt % NBUF) * TILE;
         const long koff = (long)kt * BK;
 #pragma unroll
         for (int j = 0; j < PA; ++j) glds16(a_src + (koff + j * 2) * g.lda, base + (a_dst - smem) + j * 256);
+        if (g.b_kT > 0) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) glds16(b_src + (koff + j * RB) * g.ldb, base + (b_dst - smem) + j * 256);
+            for (int j = 0; j < PB; ++j) {
+                const int t = b_t[j] + kshift;
+                const bool ok = t >= 0 && t < g.b_kT;
+                glds16(ok ? b_src + (koff + j * RB + kshift) * g.ldb : zero_src, base + (b_dst - smem) + j * 256);
+                b_t[j] += BK;
+                while (b_t[j] >= g.b_kT) b_t[j] -= g.b_kT;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PB; ++j) glds16(b_src + (koff + j * RB) * g.ldb, base + (b_dst - smem) + j * 256);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -261,7 +286,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     static const bool off = AS_DIAG_SET("AS_NO_WGRAD");  // ablation: the general kernel
     if (off) return 0;
-    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->b_kT > 0 || g->act != 0 || g->bias) return 0;
+    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->act != 0 || g->bias) return 0;
+    if (g->b_kT > 0 && (g->a_off || g->b_off || g->c_off)) return 0;   // shifted operand: linear batch strides only
     if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return 0;
     const bool grouped = g->a_off || g->b_off || g->c_off;
     if (!grouped && (g->a_batch % 4 || g->b_batch % 4)) return 0;
@@ -287,7 +313,8 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     const long tiles = (long)k.tiles_m * k.tiles_n * g->batch;
     static const bool all_shapes = AS_DIAG_SET("AS_WGRAD_ALL");  // tuning aid: also the shapes below
     // too little work to give every CU a 128-row tile over >= 256 frames: the general kernel's 64 x 64 tiles spread it better
-    if (!all_shapes && tiles * (g->K / 256) < 256) return 0;
+    static const int min_work = AS_DIAG_INT("AS_WGRAD_MIN_WORK", 256);   // tiles x 256-deep k-chunks
+    if (!all_shapes && tiles * (g->K / 256) < min_work) return 0;
     // split K so that the launch has about `target` workgroups (one per CU and round); cost model in DESIGN.md 5
     static const int target_env = AS_DIAG_INT("AS_WGRAD_TARGET", 0);
     static const int bk = AS_DIAG_INT("AS_WGRAD_BK", 32);

@@ -529,6 +529,20 @@ def test_full_width_model_matches_reference_fixture(dev):
     # reference is to itself: every quantile within 1.5x (the maximum, a single tensor, within 2x).
     q = (0.5, 0.9, 0.99, 1.0)
     got_n, got_s = np.quantile(norm_err, q), np.quantile(slice_err, q)
+    # by depth: the heads + output trunk have few ReLU decisions between them and the loss, the last decoder layer a few more
+    def group_of(k):   # names are the reference's state_dict keys
+        if k.startswith(("predictors.", "linear.")):
+            return "heads+trunk"
+        if k.startswith("decoder.layers."):
+            return "decoder." + k.split(".")[2]
+        return k.split(".")[0]
+    groups = {}
+    for i, k in enumerate(names):
+        groups.setdefault(group_of(k), []).append(i)
+    group_stats = {gname: {"tensors": len(idx), "norm_err_max": float(norm_err[idx].max()), "slice_err_max": float(slice_err[idx].max()),
+                           "slice_err_median": float(np.median(slice_err[idx]))} for gname, idx in sorted(groups.items())}
+    for gname, st in group_stats.items():
+        print(f"  {gname:14s} {st}")
     print("full-width transformer gradients, quantiles 50/90/99/100 % over", len(names), "tensors")
     print("  norm error          : this path vs reference", got_n, "  reference vs itself", g["self_norm_q"])
     print("  slice error / max|g|: this path vs reference", got_s, "  reference vs itself", g["self_slice_q"])
@@ -539,7 +553,8 @@ def test_full_width_model_matches_reference_fixture(dev):
             json.dump({"quantiles": q, "norm_err": got_n.tolist(), "slice_err": got_s.tolist(),
                        "reference_self_norm_err": g["self_norm_q"].tolist(), "reference_self_slice_err": g["self_slice_q"].tolist(),
                        "contours_valid": worst_valid, "contours_padded": worst_pad,
-                       "worst_tensor": names[int(slice_err.argmax())]}, f, indent=1)
+                       "worst_tensor": names[int(slice_err.argmax())], "by_depth": group_stats,
+                       "sample_names": names[:5] + names[-5:]}, f, indent=1)
     except OSError:
         pass
     for i in range(4):
