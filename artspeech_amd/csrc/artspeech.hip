@@ -25,6 +25,7 @@ namespace {
 
 constexpr int D = AS_HEAD_HIDDEN;
 constexpr int64_t SLAB_FLOATS = 16LL << 20;  // 64 MB of split-K partial tiles per stream
+constexpr int64_t SLAB2_FLOATS = 28LL << 20; // first side stream: the partial tiles of ALL head weight gradients in one launch
 
 struct Carve {
     int64_t off = 0;
@@ -52,21 +53,23 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.b2f = c.take(A * D);
     w.w3f = c.take(A * as_round_up(O, 32) * D);  // rows O .. Opad-1 of every head are zeros (head_fold)
     w.b3f = c.take(A * O);
-    w.r1 = c.take(rows * A * D);
     w.r1hat = c.take(rows * A * D);
     w.rstd1 = c.take(rows * A);
-    w.r2 = c.take(rows * A * D);
     w.r2hat = c.take(rows * A * D);
     w.rstd2 = c.take(rows * A);
     w.dpre3 = c.take(rows * A * O);
     w.dz2 = c.take(rows * A * D);
     w.dz1 = c.take(rows * A * D);
+    // pre-normalisation activations of the UNFUSED forward path only (as_lin_try declined): they live where the backward's
+    // dz1 / dz2 will go, which nothing touches before the backward (the fused path never materialises them)
+    w.r1 = w.dz1;
+    w.r2 = w.dz2;
     w.dxhat = c.take(rows * H);
     w.dw1f = c.take(A * D * H);
     w.dw2f = c.take(A * D * D);
     w.dw3f = c.take(A * O * D);
     w.slab = c.take(SLAB_FLOATS);   // split-K partial tiles of the weight-gradient GEMMs (main stream)
-    w.slab2 = c.take(SLAB_FLOATS);  // same, for GEMMs issued on the side stream
+    w.slab2 = c.take(SLAB2_FLOATS); // same, for GEMMs issued on the side stream
     w.slab3 = c.take(SLAB_FLOATS);  // same, second side stream
     w.bits1 = c.take(rows * A * (D / 64) * 2);  // ReLU masks of r1 / r2: one bit per element (64-bit words, 16-byte aligned)
     w.bits2 = c.take(rows * A * (D / 64) * 2);
@@ -283,17 +286,63 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     return 0;
 }
 
+// trunk (optional): the trunk Linear's weight gradient dzlin^T . y1 rides in the same launch (ArtSpeech: N = 2H = 256)
+struct TrunkJob { const float* dz; const float* y; float* dW; float* db; int H; };
+
 int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* G, float* ws, float* slab,
-                hipStream_t st, const float* dpre3_in = nullptr, int cu_budget = 0) {
+                hipStream_t st, const float* dpre3_in = nullptr, int cu_budget = 0, long slab_floats = SLAB_FLOATS,
+                const TrunkJob* trunk = nullptr) {
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
     // each weight-gradient GEMM also emits the bias gradient = column sums of its A operand
     const float* dpre3 = dpre3_in ? dpre3_in : ws + w.dpre3;
-    AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
-    AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
-    AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
+    // ---- all of them as ONE launch of 128 x 256 tiles + one reduce (wgrad_f32.hip, as_wgrad_multi).  Layer 1 is posed
+    // transposed (dW1'^T = xhat^T . dz1: 11 tiles of 128 x 256 like the others instead of 22 of 128 x 128): its result is
+    // stored transposed and its bias gradient is the column sum of the B operand.
+    int took = 0;
+    if (R % 32 == 0 && R >= 512) {
+        as_wgrad_job jobs[4] = {};
+        as_gemm& g3 = jobs[0].g;
+        g3.A = dpre3; g3.a_i = 1; g3.a_k = AO; g3.a_batch = O; g3.M = O;
+        g3.B = ws + w.r2hat; g3.b_j = 1; g3.b_k = AD; g3.b_batch = D; g3.N = D;
+        g3.C = ws + w.dw3f; g3.ldc = D; g3.c_batch = (long)O * D; g3.K = R; g3.batch = A;
+        g3.colsum = G + L.b3; g3.colsum_batch = O;
+        as_gemm& g2 = jobs[1].g;
+        g2 = g3;
+        g2.A = ws + w.dz2; g2.a_k = AD; g2.a_batch = D; g2.M = D;
+        g2.B = ws + w.r1hat;
+        g2.C = ws + w.dw2f; g2.c_batch = (long)D * D;
+        g2.colsum = G + L.b2; g2.colsum_batch = D;
+        as_gemm& g1 = jobs[2].g;
+        g1 = g3;
+        g1.A = ws + w.xhat; g1.a_k = H; g1.a_batch = 0; g1.M = H;
+        g1.B = ws + w.dz1;
+        g1.C = ws + w.dw1f; g1.ldc = H; g1.c_batch = (long)D * H;
+        g1.colsum = nullptr; g1.colsum_batch = 0;
+        jobs[2].colsum_b = G + L.b1; jobs[2].colsum_b_batch = D; jobs[2].c_trans = 1;
+        int n = 3;
+        if (trunk && 2 * trunk->H == 256) {
+            as_gemm& gt = jobs[3].g;
+            gt.A = trunk->dz; gt.a_i = 1; gt.a_k = trunk->H; gt.M = trunk->H;
+            gt.B = trunk->y; gt.b_j = 1; gt.b_k = 2 * trunk->H; gt.N = 2 * trunk->H;
+            gt.C = trunk->dW; gt.ldc = 2 * trunk->H; gt.K = R; gt.batch = 1;
+            gt.colsum = trunk->db; gt.colsum_batch = 0;
+            n = 4;
+        }
+        AS_PROF("headb.dw_fused", st);
+        took = as_wgrad_multi(jobs, n, slab, slab_floats, cu_budget, st);
+        AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
+        if (took && n == 3 && trunk) took = 2;   // the trunk's did not ride along
+    }
+    if (!took) {
+        AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
+        AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
+        AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
+    }
+    if (trunk && took != 1)
+        AS_STEP("trunkb.dw", st, gemm_tn(trunk->dz, trunk->H, trunk->y, 2 * trunk->H, trunk->dW, 2 * trunk->H, trunk->H, 2 * trunk->H, R, st, slab, trunk->db, 0));
     // unfold the LayerNorm affines: the three layers in one launch
     const float* const dWf[3] = {ws + w.dw3f, ws + w.dw2f, ws + w.dw1f};
     const float* const dbf[3] = {G + L.b3, G + L.b2, G + L.b1};
@@ -581,8 +630,8 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
     const int side_cus = sd ? 192 : 0;  // the recurrence's 2 * B workgroups hold 64 CUs while the side stream works
-    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus));
-    AS_STEP("trunkb.dw", s2, gemm_tn(dzlin, H, ws + w.y1, 2 * H, G + L.lin_w, 2 * H, H, 2 * H, R, s2, sl2, G + L.lin_b, 0));
+    const TrunkJob trunk{dzlin, ws + w.y1, G + L.lin_w, G + L.lin_b, H};
+    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus, sd ? SLAB2_FLOATS : SLAB_FLOATS, &trunk));
     AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     {
         // input gradient of GRU layer 1: [R][6H] . [6H][2H].  (diagnostic build, AS_DX1_LIN: the LDS-DMA kernel of the head

@@ -5,6 +5,16 @@
 // wgrad_f32.hip: weight-gradient shapes (both operands reduction-strided, long reduction).  1 = taken and launched,
 // 0 = not a shape for this kernel (the caller continues with the general kernel), < 0 = error.
 int as_wgrad_try(const as_gemm* g, hipStream_t st);
+// Several weight-gradient problems of the same reduction length (a_i == b_j == 1, linear batch strides, N > 128) as ONE
+// launch of 128 x 256 tiles + one reduce launch.  g.splitk_ws / cu_budget of the jobs are ignored (slab, cu_budget here).
+// colsum_b (optional): column sums of the B operand [batch][N] (the bias gradient when the problem is posed transposed);
+// c_trans: the result is stored transposed, C[batch][n * ldc + m].  1 = launched, 0 = not a case (caller falls back), < 0 = error.
+struct as_wgrad_job {
+    as_gemm g;
+    float* colsum_b; long colsum_b_batch;
+    int c_trans;
+};
+int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st);
 
 // lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):
 //   C[bz] = epilogue(A[bz] [M][K] . B[bz]),  B[bz] = [N][K] (b_kc: forward) or [K][N] (backward); N <= 256, K % 32 == 0.

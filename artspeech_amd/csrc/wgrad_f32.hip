@@ -20,6 +20,11 @@
 //   * deterministic split-K over slabs with a wide reduce kernel (fixed summation order: results do not depend on the
 //     order in which workgroups are scheduled); the split comes from a small cost model over whole rounds of workgroups
 //     and slab traffic, for the number of CUs the caller expects to be free (as_gemm.cu_budget).
+//   * SEVERAL problems in one launch (as_wgrad_multi): the weight gradients of the three head layers and of the trunk Linear
+//     are 46 tiles of 128 x 256 under K = 6400 in all.  Launched one by one, each fills 176 of 256 CUs with one long
+//     workgroup per CU and pays its own prologue, tail and reduce launch; as ONE grid of k-chunks of every problem the
+//     dispatcher keeps every free CU busy until the work is gone, and one reduce launch sums all slabs.  A problem may ask
+//     for the column sums of its B operand (bias gradient of the transposed formulation) and for a transposed result.
 #include <cstdlib>
 
 #include "gemm_internal.h"
@@ -33,6 +38,8 @@ constexpr int KALIGN = 32;   // reduction chunks are multiples of both k-tile de
 
 // source of the shifted B operand's out-of-sequence rows (b_kT > 0): one row of zeros the DMA can read
 __device__ __attribute__((aligned(16))) float g_zero_row[256];
+
+constexpr int MAXP = 6;   // problems per launch
 
 struct WgradK {
     const float* A; const float* B; float* C;
@@ -48,6 +55,11 @@ struct WgradK {
     float* slab;     // [splitk][batch][M][N]
     float* cs_slab;  // [splitk][batch][M]
     float* colsum; long colsum_batch;
+    // multi-problem launches: first work item / first reduce thread of this problem; optional column sums of B
+    // (colsum_b [batch][N], slabs [splitk][batch][N]); c_trans: the result is stored transposed, C[n * ldc + m]
+    long item0, red0;
+    float* colsum_b; long colsum_b_batch; float* csb_slab;
+    int c_trans;
 #ifdef AS_DIAG
     int abl;  // diagnostic ablation (AS_WGRAD_ABL=1): no global loads after the first two k-tiles (matrix work only)
 #else
@@ -69,8 +81,14 @@ __device__ __forceinline__ void glds16(const float* src, float* dst) {
 
 // BK = 32: one workgroup per CU (144 KB of LDS at BN = 256, two k-tiles = 96 KB in flight).  BK = 16: 72 KB, two workgroups
 // per CU -- the partner's MFMAs cover this one's barriers, prologue and epilogue.
+struct WgradMulti {
+    int n, per_xcd;
+    long total_items, total_red;
+    WgradK p[MAXP];
+};
+
 template <int BN, int BK>
-__global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK g) {
+__global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMulti mm) {
     constexpr int WN = BN / 4, TN = WN / 32, TM = 2;   // 2 x 4 waves; a wave owns 64 rows x WN columns
     constexpr int TILE = BK * (BM + BN);                // floats per ring slot: A image [BK][BM] then B image [BK][BN]
     constexpr int PA = BK * BM / 256 / 8;               // 1-KiB DMA pieces of A per wave and k-tile (2)
@@ -85,9 +103,15 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
     // (batch, k-slab, n-tile) combination, which read the same B panel, sit on one XCD (two at a seam), and the XCDs get
     // equal shares whatever the counts are.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    if (slot >= g.per_xcd) return;
-    const long item = (long)xcd * g.per_xcd + slot;
-    if (item >= g.ncombos * g.tiles_m) return;
+    if (slot >= mm.per_xcd) return;
+    long item = (long)xcd * mm.per_xcd + slot;
+    if (item >= mm.total_items) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < mm.n && item >= mm.p[i].item0) pi = i;
+    const WgradK& g = mm.p[pi];
+    item -= g.item0;
     const int tm = (int)(item % g.tiles_m);
     const long combo = item / g.tiles_m;
     const int tn = (int)(combo % g.tiles_n);
@@ -102,6 +126,7 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool do_cs = g.colsum != nullptr && tn == 0;
+    const bool do_csb = g.colsum_b != nullptr && tm == 0;
 
     // DMA sources.  A piece = 2 rows x 128 floats: lanes 0-31 row r, lanes 32-63 row r + 1.  Columns beyond M / N are
     // redirected to the last valid float4 of the row: they only feed output rows / columns that are never stored.
@@ -151,6 +176,8 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float cs = 0.f;  // bias gradient: this thread sums column tid & 127 over rows (tid >> 7) * 8 .. + 7 of every k-tile
+    float csb = 0.f; // column sums of B: column tid % BN over rows (tid / BN) * CSRB .. of every k-tile
+    constexpr int CSRB = BK / (NT / BN);
 
     const int nk = (kend - kbeg) / BK;
     // Ring of NBUF = 3 slots: while k-tile t is multiplied, t + 1 and t + 2 are in flight (2 x 48 KB per CU at BN = 256).
@@ -171,6 +198,11 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
             const float* c_s = tile + (tid >> 7) * CSR * BM + (tid & 127);
 #pragma unroll
             for (int r = 0; r < CSR; ++r) cs += c_s[r * BM];
+        }
+        if (do_csb) {
+            const float* c_s = tile + BK * BM + (tid / BN) * CSRB * BN + (tid % BN);
+#pragma unroll
+            for (int r = 0; r < CSRB; ++r) csb += c_s[r * BN];
         }
         // operands of k-step kk + 1 are read before the MFMAs of k-step kk are issued (their LDS latency hides behind them)
         float av[2][TM], bv[2][TN];
@@ -211,6 +243,18 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
             else g.colsum[(long)bz * g.colsum_batch + m0 + tid] = s;
         }
     }
+    if (do_csb) {
+        __syncthreads();   // (the A-side exchange above may still be reading)
+        smem[tid] = csb;
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.N) {
+            float s = smem[tid];
+#pragma unroll
+            for (int q = 1; q < NT / BN; ++q) s += smem[q * BN + tid];
+            if (g.splitk > 1) g.csb_slab[((long)ks * g.batch + bz) * g.N + n0 + tid] = s;
+            else g.colsum_b[(long)bz * g.colsum_b_batch + n0 + tid] = s;
+        }
+    }
 
     // ---- epilogue: D[i][j], j = lane & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float* out;
@@ -233,17 +277,26 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradK 
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= g.M) continue;
-                float* c = out + (long)row * ld + col;
+                float* c = (g.splitk == 1 && g.c_trans) ? out + (long)col * ld + row : out + (long)row * ld + col;
                 *c = acc_c ? *c + acc[i][j][r] : acc[i][j][r];
             }
     }
 }
 
-// C (+)= sum over the k-slabs in slab order; the tail of the grid sums the bias-gradient slabs
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradK g) {
+// C (+)= sum over the k-slabs in slab order, every problem of the launch in one grid: per problem first the float4 groups
+// of the result, then the bias-gradient slabs (A side, then B side).  c_trans: C[n * ldc + m] (scalar stores).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradMulti mm) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= mm.total_red) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < mm.n && idx >= mm.p[i].red0) pi = i;
+    const WgradK& g = mm.p[pi];
+    idx -= g.red0;
+    if (g.splitk <= 1) return;   // that problem wrote its result directly
     const long per4 = (long)g.M * g.N / 4;
     const long total4 = (long)g.batch * per4;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx < total4) {
         const float4* s4 = reinterpret_cast<const float4*>(g.slab) + idx;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -255,7 +308,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradK g) {
         const long bz = idx / per4, rem = (idx - bz * per4) * 4;
         const long row = rem / g.N;
         const int col = (int)(rem - row * g.N);
-        float* c = g.C + (g.c_off ? g.c_off[bz] : bz * g.c_batch) + row * g.ldc + col;
+        float* cb = g.C + (g.c_off ? g.c_off[bz] : bz * g.c_batch);
+        if (g.c_trans) {
+            float* c = cb + (long)col * g.ldc + row;
+            if (g.accumulate) { s.x += c[0]; s.y += c[g.ldc]; s.z += c[2 * g.ldc]; s.w += c[3 * g.ldc]; }
+            c[0] = s.x; c[g.ldc] = s.y; c[2 * g.ldc] = s.z; c[3 * g.ldc] = s.w;
+            return;
+        }
+        float* c = cb + row * g.ldc + col;
         if (g.c_vec) {
             float4* c4 = reinterpret_cast<float4*>(c);
             if (g.accumulate) {
@@ -269,30 +329,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradK g) {
         }
         return;
     }
-    const long e = idx - total4;
-    if (g.colsum == nullptr || e >= (long)g.batch * g.M) return;
+    long e = idx - total4;
+    const long n_cs = g.colsum ? (long)g.batch * g.M : 0;
+    if (e < n_cs) {
+        float s = 0.f;
+        for (int k = 0; k < g.splitk; ++k) s += g.cs_slab[(long)k * g.batch * g.M + e];
+        const long bz = e / g.M;
+        g.colsum[bz * g.colsum_batch + (e - bz * g.M)] = s;
+        return;
+    }
+    e -= n_cs;
+    if (g.colsum_b == nullptr || e >= (long)g.batch * g.N) return;
     float s = 0.f;
-    for (int k = 0; k < g.splitk; ++k) s += g.cs_slab[(long)k * g.batch * g.M + e];
-    const long bz = e / g.M;
-    g.colsum[bz * g.colsum_batch + (e - bz * g.M)] = s;
+    for (int k = 0; k < g.splitk; ++k) s += g.csb_slab[(long)k * g.batch * g.N + e];
+    const long bz = e / g.N;
+    g.colsum_b[bz * g.colsum_b_batch + (e - bz * g.N)] = s;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
-
-// Takes the GEMM if it is a weight-gradient shape this kernel is built for (returns 1 and launches), else returns 0;
-// negative = error.  Called by as_gemm_f32 ahead of its general tile selection.
-int as_wgrad_try(const as_gemm* g, hipStream_t st) {
-    static const bool off = AS_DIAG_SET("AS_NO_WGRAD");  // ablation: the general kernel
-    if (off) return 0;
-    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->act != 0 || g->bias) return 0;
-    if (g->b_kT > 0 && (g->a_off || g->b_off || g->c_off)) return 0;   // shifted operand: linear batch strides only
-    if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return 0;
+// shape / alignment contract of one problem; fills the descriptor's operand fields.  false = not a case for this kernel.
+bool describe(const as_gemm* g, WgradK& k) {
+    if (!(g->a_i == 1 && g->b_j == 1) || g->K < 256 || g->K % KALIGN || g->act != 0 || g->bias) return false;
+    if (g->b_kT > 0 && (g->a_off || g->b_off || g->c_off)) return false;   // shifted operand: linear batch strides only
+    if (g->M % 4 || g->N % 4 || g->a_k % 4 || g->b_k % 4 || !aligned16(g->A) || !aligned16(g->B)) return false;
     const bool grouped = g->a_off || g->b_off || g->c_off;
-    if (!grouped && (g->a_batch % 4 || g->b_batch % 4)) return 0;
-    if ((long)g->M * g->N % 4) return 0;
-    WgradK k{};
+    if (!grouped && (g->a_batch % 4 || g->b_batch % 4)) return false;
+    if ((long)g->M * g->N % 4) return false;
+    k = WgradK{};
     k.A = g->A; k.B = g->B; k.C = g->C;
     k.M = g->M; k.N = g->N; k.K = g->K;
     k.lda = g->a_k; k.ldb = g->b_k; k.ldc = g->ldc;
@@ -303,7 +367,35 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
     k.accumulate = g->accumulate;
     k.c_vec = aligned16(g->C) && g->ldc % 4 == 0 && (g->c_off ? 1 : g->c_batch % 4 == 0);
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
-    #ifdef AS_DIAG
+    return true;
+}
+
+template <int BNT>
+int launch_multi(WgradMulti& mm, int bk, hipStream_t st) {
+    const dim3 grid((unsigned)(8 * mm.per_xcd));
+    if (bk == 16) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 16>), grid, dim3(NT), 0, st, mm);
+    else hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32>), grid, dim3(NT), 0, st, mm);
+    AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
+    bool any = false;
+    for (int i = 0; i < mm.n; ++i) any = any || mm.p[i].splitk > 1;
+    if (any) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((mm.total_red + 255) / 256)), dim3(256), 0, st, mm);
+        AS_LAUNCH_CHECK("as_gemm_f32(wgrad reduce)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Takes the GEMM if it is a weight-gradient shape this kernel is built for (returns 1 and launches), else returns 0;
+// negative = error.  Called by as_gemm_f32 ahead of its general tile selection.
+int as_wgrad_try(const as_gemm* g, hipStream_t st) {
+    static const bool off = AS_DIAG_SET("AS_NO_WGRAD");  // ablation: the general kernel
+    if (off) return 0;
+    WgradMulti mm{};
+    WgradK& k = mm.p[0];
+    if (!describe(g, k)) return 0;
+#ifdef AS_DIAG
     static const int abl = AS_DIAG_INT("AS_WGRAD_ABL", 0);
     k.abl = abl;
 #endif
@@ -346,20 +438,74 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
         k.cs_slab = g->splitk_ws + (long)k.splitk * per;
     }
     k.ncombos = (long)g->batch * k.splitk * k.tiles_n;
-    k.per_xcd = (int)((k.ncombos * k.tiles_m + 7) / 8);
-    const dim3 grid((unsigned)(8 * k.per_xcd));
-    if (bk == 16) {
-        if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256, 16>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((wgrad_f32_kernel<128, 16>), grid, dim3(NT), 0, st, k);
-    } else {
-        if (bn == 256) hipLaunchKernelGGL((wgrad_f32_kernel<256, 32>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(NT), 0, st, k);
+    mm.n = 1;
+    mm.total_items = k.ncombos * k.tiles_m;
+    mm.per_xcd = (int)((mm.total_items + 7) / 8);
+    mm.total_red = per / 4 + per_cs;
+    const int rc = bn == 256 ? launch_multi<256>(mm, bk, st) : launch_multi<128>(mm, bk, st);
+    return rc == 0 ? 1 : rc;
+}
+
+// Several weight-gradient problems of one reduction length as ONE launch + one reduce launch (gemm_internal.h).  Every
+// problem runs on 128 x 256 tiles (N > 128 expected) and is split over K in chunks of the same length, chosen so that the
+// grid is a few rounds of the CUs the caller expects (cu_budget, 0 = chip): many short workgroups instead of one long one
+// per CU, so the dispatcher fills every free CU and other streams' kernels get CUs as workgroups retire.
+// 1 = launched, 0 = not a case (nothing launched: the caller issues the problems one by one), < 0 = error.
+int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st) {
+    static const bool off = AS_DIAG_SET("AS_NO_WGRAD_MULTI");  // ablation: one launch per problem
+    if (off || n < 1 || n > MAXP || !slab) return 0;
+    WgradMulti mm{};
+    long tiles = 0;
+    const int K = jobs[0].g.K;
+    for (int i = 0; i < n; ++i) {
+        const as_gemm* g = &jobs[i].g;
+        WgradK& k = mm.p[i];
+        if (g->K != K || g->a_off || g->b_off || g->c_off || !describe(g, k)) return 0;
+        if (jobs[i].colsum_b && g->b_kT > 0) return 0;
+        k.tiles_m = as_cdiv(g->M, BM);
+        k.tiles_n = as_cdiv(g->N, 256);
+        k.colsum_b = jobs[i].colsum_b; k.colsum_b_batch = jobs[i].colsum_b_batch; k.c_trans = jobs[i].c_trans;
+        tiles += (long)k.tiles_m * k.tiles_n * g->batch;
     }
-    AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
-    if (k.splitk > 1) {
-        const long threads = per / 4 + per_cs;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
-        AS_LAUNCH_CHECK("as_gemm_f32(wgrad reduce)");
+    // chunk length: a multiple of 32 frames, at least 256; cost = rounds of `cus` workgroups x (chunk + fixed cost per
+    // workgroup) + slab traffic, all in units of one k-tile of 32 frames (~4 us for a 128 x 256 tile)
+    const int cus = cu_budget > 0 ? cu_budget : 256;
+    static const int chunk_env = AS_DIAG_INT("AS_WGRAD_MULTI_CHUNK", 0);   // k-tiles per workgroup (tuning aid)
+    const int nkt = K / 32;
+    int best_chunk = nkt;
+    double best = 1e30;
+    for (int chunk = 8; chunk <= nkt; ++chunk) {
+        const long S = as_cdiv(nkt, chunk);
+        const long W = tiles * S;
+        const double rounds = (double)((W + cus - 1) / cus);
+        const double cost = rounds * (chunk + 1.0) + 0.016 * W;   // 128 KB of slab written + read per workgroup at ~4 TB/s
+        if (cost < best - 1e-9) best = cost, best_chunk = chunk;
     }
-    return 1;
+    if (chunk_env > 0) best_chunk = chunk_env < nkt ? chunk_env : nkt;
+    long off_f = 0, item0 = 0, red0 = 0;
+    for (int i = 0; i < n; ++i) {
+        WgradK& k = mm.p[i];
+        k.kchunk = best_chunk * 32;
+        k.splitk = as_cdiv(K, k.kchunk);
+        const long per = (long)k.batch * k.M * k.N;
+        const long per_cs = k.colsum ? (long)k.batch * k.M : 0, per_csb = k.colsum_b ? (long)k.batch * k.N : 0;
+        if (k.splitk > 1) {
+            k.slab = slab + off_f;
+            k.cs_slab = k.slab + (long)k.splitk * per;
+            k.csb_slab = k.cs_slab + (long)k.splitk * per_cs;
+            off_f += as_round_up((long)k.splitk * (per + per_cs + per_csb), 64);
+        }
+        k.ncombos = (long)k.batch * k.splitk * k.tiles_n;
+        k.item0 = item0;
+        k.red0 = red0;
+        item0 += k.ncombos * k.tiles_m;
+        red0 += per / 4 + per_cs + per_csb;
+    }
+    if (off_f > slab_floats) return 0;
+    mm.n = n;
+    mm.total_items = item0;
+    mm.total_red = red0;
+    mm.per_xcd = (int)((item0 + 7) / 8);
+    const int rc = launch_multi<256>(mm, 32, st);
+    return rc == 0 ? 1 : rc;
 }

@@ -62,6 +62,8 @@ def gemm_flops(rows):
         "grub.dw_hh": 2 * 2 * rows * 2 * 3 * H * H,   # two layers x two directions
         "trunk.linear": 2 * rows * H * 2 * H, "trunkb.dw": 2 * rows * H * 2 * H, "trunkb.dx": 2 * rows * H * 2 * H,
         "gru.table0": 2 * V * 6 * H * E, "grub.dw_ih0": 2 * V * 6 * H * E, "grub.demb": 2 * V * 6 * H * E,
+        # the head layers' and the trunk's weight gradients as ONE multi-problem launch (wgrad_f32.hip, as_wgrad_multi)
+        "headb.dw_fused": 2 * rows * A * 2 * N * D + 2 * rows * A * D * D + 2 * rows * A * D * H + 2 * rows * H * 2 * H,
     }
 
 
@@ -73,7 +75,7 @@ GEMM_FAMILIES = {
     "input gradients (C = A.B): lin_f32_kernel<64, false, 2> [head dx 3, 2 + LayerNorm/ReLU backward] + gemm_f32_kernel<*, *, true, false, true>":
         ["headb.dx3", "headb.dx2", "headb.dx1", "trunkb.dx", "grub.dx1", "grub.demb"],
     "weight gradients (C = A^T.B): wgrad_f32_kernel<*, 32> [heads] + gemm_f32_kernel<64, 64, false, false, true> [GRU, trunk]":
-        ["headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
+        ["headb.dw_fused", "headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
 }
 
 

@@ -844,6 +844,10 @@ def gen_transformer_c4(tmod, dataset, p2a_metrics, helpers):
         torch.set_num_threads(nt)
     ne = np.abs(again["gnorm"] - arrays["gnorm"]) / arrays["gnorm"]
     se = np.abs(again["gslice"] - arrays["gslice"]).max(1) / arrays["gmax"]
+    # per tensor as well (the test groups them by depth: heads, last decoder layer, ..., encoder) and per contour position
+    cr = np.abs(again["out_slices"] - arrays["out_slices"]) / (1e-4 * np.abs(arrays["out_slices"]) + 2e-6)
+    arrays.update(self_norm_err=ne.astype(np.float32), self_slice_err=se.astype(np.float32),
+                  self_contour_ratio=cr.reshape(cr.shape[0], -1).max(1))
     arrays.update(self_norm_q=np.quantile(ne, C4_QUANTILES), self_slice_q=np.quantile(se, C4_QUANTILES),
                   self_contour_diff=np.float64(np.abs(again["out_slices"] - arrays["out_slices"]).max()),
                   self_loss_diff=np.float64(abs(float(again["loss"]) - float(arrays["loss"]))), self_threads=np.array([nt, 1]))

@@ -298,6 +298,57 @@ def test_single_head_vs_reference_fixture(dev, name):
         assert_grad_close(got, grads[k], f"{name}: {k}")
 
 
+def test_head_stack_fused_weight_gradients_vs_oracle(dev):
+    """as_head_fwd / as_head_bwd at a row count that takes the fused paths (lin_f32_kernel layers, ONE multi-problem
+    weight-gradient launch incl. the transposed layer-1 problem and its B-side column sums) against the fp64 oracle:
+    A = 3 heads, 1536 frames, non-trivial LayerNorm affines, every parameter gradient element-wise."""
+    from artspeech_amd import _lib
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import _build_views, _numel
+    from oracle import artspeech_oracle as O
+    L = _lib.lib()
+    A, H, N, rows = 3, 128, 50, 1536
+    dims = _lib.Dims(1, A, 1, H, N, 1)
+    lay = _lib.layout(dims)
+    rng = np.random.RandomState(7)
+    views = {k: v for k, v in _build_views(dims, lay).items() if k.startswith("predictors.")}
+    flat = torch.zeros(lay.total)
+    params = {}
+    for k, (off, shape) in views.items():
+        n = _numel(shape)
+        if k.endswith((".linear.0.weight", ".linear.3.weight", ".linear.6.weight")):
+            v = rng.uniform(0.7, 1.3, n)
+        elif k.endswith((".linear.0.bias", ".linear.3.bias", ".linear.6.bias")):
+            v = rng.uniform(-0.2, 0.2, n)
+        else:
+            fan = shape[-1] if len(shape) > 1 else 256
+            v = rng.uniform(-1, 1, n) / np.sqrt(fan)
+        params[k] = v.astype(np.float32).reshape(shape)
+        flat[off:off + n] = torch.from_numpy(params[k]).reshape(-1)
+    x = rng.randn(rows, H).astype(np.float32)
+    dsig = (rng.randn(rows, A, 2, N) * 1e-3).astype(np.float32)
+    flat_d, x_d, dsig_d = flat.to(dev), T_(x, dev), T_(dsig, dev)
+    out = torch.empty((rows, A, 2, N), device=dev)
+    ws = torch.empty(L.as_head_workspace_floats(C.byref(dims), rows), device=dev)
+    _lib.check(L.as_head_fwd(C.byref(dims), C.byref(lay), _lib.ptr(flat_d), _lib.ptr(x_d), rows, _lib.ptr(out), _lib.ptr(ws), 1, _lib.stream_ptr()))
+    G = torch.zeros_like(flat_d)
+    dx = torch.empty((rows, H), device=dev)
+    _lib.check(L.as_head_bwd(C.byref(dims), C.byref(lay), _lib.ptr(flat_d), _lib.ptr(out), _lib.ptr(dsig_d), rows, _lib.ptr(dx), _lib.ptr(G),
+                             _lib.ptr(ws), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    Gc, dx_ref = G.cpu(), np.zeros((rows, H))
+    for a in range(A):
+        p = {k[len(f"predictors.{a}."):]: v.astype(np.float64) for k, v in params.items() if k.startswith(f"predictors.{a}.")}
+        pre, cache = O.predictor_fwd(x.astype(np.float64), p)
+        sig = 1 / (1 + np.exp(-pre))
+        assert_close(out[:, a].cpu().numpy(), sig, what=f"head {a} out")
+        dxa, ga = O.predictor_bwd(dsig[:, a].astype(np.float64) * sig * (1 - sig), cache, p)
+        dx_ref += dxa
+        for k, gref in ga.items():
+            off, shape = views[f"predictors.{a}.{k}"]
+            assert_grad_close(Gc[off:off + _numel(shape)].view(shape).numpy(), gref, f"fused head stack: predictors.{a}.{k}")
+    assert_grad_close(dx.cpu().numpy(), dx_ref, "fused head stack: dx")
+
+
 # ------------------------------------------------------------------------------------------- models
 def _load_model(cls, g, dev, **kw):
     w, grads = split_wg(g)
