@@ -34,7 +34,8 @@ class Layout(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64), ("dout_presigmoid", C.c_int32)]
+    _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64), ("dout_presigmoid", C.c_int32),
+                ("defer_dw2", C.c_int32), ("fold_wait_event", C.c_void_p)]
 
 
 class Gemm(C.Structure):
@@ -61,6 +62,7 @@ PROTOTYPES = {
     "as_artspeech_workspace_floats": (_I64, [_DIMS, _I32, _I32]),
     "as_artspeech_fwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _I32, C.POINTER(Opts), _P]),
     "as_artspeech_bwd": (_I32, [_DIMS, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P, C.POINTER(Opts), _P]),
+    "as_artspeech_dw2": (_I32, [_DIMS, _P, _I32, _I32, _P, _P, _P]),
     "as_gru_bidir_fwd": (_I32, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gru_bidir_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gemm_f32": (_I32, [C.POINTER(Gemm), _P]),

@@ -289,71 +289,94 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
 // trunk (optional): the trunk Linear's weight gradient dzlin^T . y1 rides in the same launch (ArtSpeech: N = 2H = 256)
 struct TrunkJob { const float* dz; const float* y; float* dW; float* db; int H; };
 
+// part: 0 = everything; 1 = layers 3 and 1 (+ the trunk's); 2 = layer 2 + the LayerNorm-affine unfold of all three.  The
+// model's backward issues part 1 beside the layer-1 recurrence and part 2 beside the layer-0 recurrence: each is one round
+// of <= 192 long-lived workgroups, so that the GRU input-gradient GEMM between the two recurrences finds the chip free
+// (a single launch of all four problems kept 184 CUs for ~240 us and that GEMM waited for CUs: 113 us instead of 52).
 int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t rows, float* G, float* ws, float* slab,
                 hipStream_t st, const float* dpre3_in = nullptr, int cu_budget = 0, long slab_floats = SLAB_FLOATS,
-                const TrunkJob* trunk = nullptr) {
+                const TrunkJob* trunk = nullptr, int part = 0, int unfold_layers = -1) {
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
     const int R = (int)rows;
     const long AD = (long)A * D, AO = (long)A * O;
     // each weight-gradient GEMM also emits the bias gradient = column sums of its A operand
     const float* dpre3 = dpre3_in ? dpre3_in : ws + w.dpre3;
-    // ---- all of them as ONE launch of 128 x 256 tiles + one reduce (wgrad_f32.hip, as_wgrad_multi).  Layer 1 is posed
+    // ---- several of them as ONE launch of 128 x 256 tiles + one reduce (wgrad_f32.hip, as_wgrad_multi).  Layer 1 is posed
     // transposed (dW1'^T = xhat^T . dz1: 11 tiles of 128 x 256 like the others instead of 22 of 128 x 128): its result is
     // stored transposed and its bias gradient is the column sum of the B operand.
-    int took = 0;
-    if (R % 32 == 0 && R >= 512) {
-        as_wgrad_job jobs[4] = {};
-        as_gemm& g3 = jobs[0].g;
-        g3.A = dpre3; g3.a_i = 1; g3.a_k = AO; g3.a_batch = O; g3.M = O;
-        g3.B = ws + w.r2hat; g3.b_j = 1; g3.b_k = AD; g3.b_batch = D; g3.N = D;
-        g3.C = ws + w.dw3f; g3.ldc = D; g3.c_batch = (long)O * D; g3.K = R; g3.batch = A;
-        g3.colsum = G + L.b3; g3.colsum_batch = O;
-        as_gemm& g2 = jobs[1].g;
-        g2 = g3;
-        g2.A = ws + w.dz2; g2.a_k = AD; g2.a_batch = D; g2.M = D;
-        g2.B = ws + w.r1hat;
-        g2.C = ws + w.dw2f; g2.c_batch = (long)D * D;
-        g2.colsum = G + L.b2; g2.colsum_batch = D;
-        as_gemm& g1 = jobs[2].g;
-        g1 = g3;
-        g1.A = ws + w.xhat; g1.a_k = H; g1.a_batch = 0; g1.M = H;
-        g1.B = ws + w.dz1;
-        g1.C = ws + w.dw1f; g1.ldc = H; g1.c_batch = (long)D * H;
-        g1.colsum = nullptr; g1.colsum_batch = 0;
-        jobs[2].colsum_b = G + L.b1; jobs[2].colsum_b_batch = D; jobs[2].c_trans = 1;
-        int n = 3;
-        if (trunk && 2 * trunk->H == 256) {
-            as_gemm& gt = jobs[3].g;
+    as_wgrad_job jobs[4] = {};
+    as_gemm& g3 = jobs[0].g;
+    g3.A = dpre3; g3.a_i = 1; g3.a_k = AO; g3.a_batch = O; g3.M = O;
+    g3.B = ws + w.r2hat; g3.b_j = 1; g3.b_k = AD; g3.b_batch = D; g3.N = D;
+    g3.C = ws + w.dw3f; g3.ldc = D; g3.c_batch = (long)O * D; g3.K = R; g3.batch = A;
+    g3.colsum = G + L.b3; g3.colsum_batch = O;
+    as_gemm& g1 = jobs[1].g;
+    g1 = g3;
+    g1.A = ws + w.xhat; g1.a_k = H; g1.a_batch = 0; g1.M = H;
+    g1.B = ws + w.dz1;
+    g1.C = ws + w.dw1f; g1.ldc = H; g1.c_batch = (long)D * H;
+    g1.colsum = nullptr; g1.colsum_batch = 0;
+    jobs[1].colsum_b = G + L.b1; jobs[1].colsum_b_batch = D; jobs[1].c_trans = 1;
+    as_wgrad_job job2{};
+    as_gemm& g2 = job2.g;
+    g2 = g3;
+    g2.A = ws + w.dz2; g2.a_k = AD; g2.a_batch = D; g2.M = D;
+    g2.B = ws + w.r1hat;
+    g2.C = ws + w.dw2f; g2.c_batch = (long)D * D;
+    g2.colsum = G + L.b2; g2.colsum_batch = D;
+    const bool multi_ok = R % 32 == 0 && R >= 512;
+    if (part == 0 || part == 1) {
+        int n = 2;
+        const bool trunk_rides = trunk && 2 * trunk->H == 256;
+        if (trunk_rides) {
+            as_gemm& gt = jobs[n].g;
             gt.A = trunk->dz; gt.a_i = 1; gt.a_k = trunk->H; gt.M = trunk->H;
             gt.B = trunk->y; gt.b_j = 1; gt.b_k = 2 * trunk->H; gt.N = 2 * trunk->H;
             gt.C = trunk->dW; gt.ldc = 2 * trunk->H; gt.K = R; gt.batch = 1;
             gt.colsum = trunk->db; gt.colsum_batch = 0;
-            n = 4;
+            ++n;
         }
-        AS_PROF("headb.dw_fused", st);
-        took = as_wgrad_multi(jobs, n, slab, slab_floats, cu_budget, st);
-        AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
-        if (took && n == 3 && trunk) took = 2;   // the trunk's did not ride along
+        if (part == 0) jobs[n++] = job2;
+        int took = 0;
+        if (multi_ok) {
+            AS_PROF(part == 0 ? "headb.dw_fused" : "headb.dw31", st);
+            took = as_wgrad_multi(jobs, n, slab, slab_floats, cu_budget, st);
+            AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
+        }
+        if (!took) {
+            AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
+            AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
+            if (part == 0)
+                AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
+        }
+        if (trunk && !(took && trunk_rides))
+            AS_STEP("trunkb.dw", st, gemm_tn(trunk->dz, trunk->H, trunk->y, 2 * trunk->H, trunk->dW, 2 * trunk->H, trunk->H, 2 * trunk->H, R, st, slab, trunk->db, 0));
+    } else {
+        int took = 0;
+        if (multi_ok) {
+            AS_PROF("headb.dw2", st);
+            took = as_wgrad_multi(&job2, 1, slab, slab_floats, cu_budget, st);
+            AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
+        }
+        if (!took)
+            AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
     }
-    if (!took) {
-        AS_STEP("headb.dw3", st, gemm_tn(dpre3, AO, ws + w.r2hat, AD, ws + w.dw3f, D, O, D, R, st, slab, G + L.b3, O, A, O, D, (long)O * D, 0, 0, 0, cu_budget));
-        AS_STEP("headb.dw2", st, gemm_tn(ws + w.dz2, AD, ws + w.r1hat, AD, ws + w.dw2f, D, D, D, R, st, slab, G + L.b2, D, A, D, D, (long)D * D, 0, 0, 0, cu_budget));
-        AS_STEP("headb.dw1", st, gemm_tn(ws + w.dz1, AD, ws + w.xhat, H, ws + w.dw1f, H, (int)AD, H, R, st, slab, G + L.b1, 0, 1, 0, 0, 0, 0, 0, 0, cu_budget));
-    }
-    if (trunk && took != 1)
-        AS_STEP("trunkb.dw", st, gemm_tn(trunk->dz, trunk->H, trunk->y, 2 * trunk->H, trunk->dW, 2 * trunk->H, trunk->H, 2 * trunk->H, R, st, slab, trunk->db, 0));
-    // unfold the LayerNorm affines: the three layers in one launch
-    const float* const dWf[3] = {ws + w.dw3f, ws + w.dw2f, ws + w.dw1f};
-    const float* const dbf[3] = {G + L.b3, G + L.b2, G + L.b1};
-    const float* const Wp[3] = {P + L.w3, P + L.w2, P + L.w1};
-    const float* const gm[3] = {P + L.ln3_g, P + L.ln2_g, P + L.ln1_g};
-    const float* const bt[3] = {P + L.ln3_b, P + L.ln2_b, P + L.ln1_b};
-    float* const dWo[3] = {G + L.w3, G + L.w2, G + L.w1};
-    float* const dgm[3] = {G + L.ln3_g, G + L.ln2_g, G + L.ln1_g};
-    float* const dbt[3] = {G + L.ln3_b, G + L.ln2_b, G + L.ln1_b};
-    const int Rs[3] = {O, D, D}, Ks[3] = {D, D, H};
-    AS_STEP("headb.unfold", st, as_unfold3(dWf, dbf, Wp, gm, bt, dWo, dgm, dbt, Rs, Ks, A, st));
+    // unfold the LayerNorm affines (bit 0: layer 3, bit 1: layer 2, bit 2: layer 1; default: all three once everything is
+    // there, i.e. with part 0 or 2): one launch
+    if (unfold_layers < 0) unfold_layers = part == 1 ? 0 : 7;
+    if (unfold_layers == 0) return 0;
+    const float* dWf[3]; const float* dbf[3]; const float* Wp[3]; const float* gm[3]; const float* bt[3];
+    float* dWo[3]; float* dgm[3]; float* dbt[3];
+    int Rs[3], Ks[3], cnt = 0;
+    auto add = [&](int64_t dwf, int64_t b, int64_t wgt, int64_t g_, int64_t b_, int r, int k) {
+        dWf[cnt] = ws + dwf; dbf[cnt] = G + b; Wp[cnt] = P + wgt; gm[cnt] = P + g_; bt[cnt] = P + b_;
+        dWo[cnt] = G + wgt; dgm[cnt] = G + g_; dbt[cnt] = G + b_; Rs[cnt] = r; Ks[cnt] = k; ++cnt;
+    };
+    if (unfold_layers & 1) add(w.dw3f, L.b3, L.w3, L.ln3_g, L.ln3_b, O, D);
+    if (unfold_layers & 2) add(w.dw2f, L.b2, L.w2, L.ln2_g, L.ln2_b, D, D);
+    if (unfold_layers & 4) add(w.dw1f, L.b1, L.w1, L.ln1_g, L.ln1_b, D, H);
+    AS_STEP("headb.unfold", st, as_unfold3(dWf, dbf, Wp, gm, bt, dWo, dgm, dbt, Rs, Ks, A, st, cnt));
     return 0;
 }
 
@@ -478,14 +501,16 @@ extern "C" int as_artspeech_layout(const as_dims* d, as_layout* out) {
     L.ln1_b = c.take(A * H);
     L.w1 = c.take(A * D * H);
     L.b1 = c.take(A * D);
-    L.ln2_g = c.take(A * D);
-    L.ln2_b = c.take(A * D);
-    L.w2 = c.take(A * D * D);
-    L.b2 = c.take(A * D);
     L.ln3_g = c.take(A * D);
     L.ln3_b = c.take(A * D);
     L.w3 = c.take(A * 2 * N * D);
     L.b3 = c.take(A * 2 * N);
+    // last: the group whose gradient a pipelined training loop computes one step late (as_opts.defer_dw2): one
+    // contiguous slice [ln2_g, total) for its all-reduce and its Adam update
+    L.ln2_g = c.take(A * D);
+    L.ln2_b = c.take(A * D);
+    L.w2 = c.take(A * D * D);
+    L.b2 = c.take(A * D);
     L.total = c.off;
     *out = L;
     return 0;
@@ -536,6 +561,10 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
     // the weight folds depend on the parameters only: run them on the side stream beside the recurrences
     StreamState* sd = d->simple ? nullptr : side_for(st);
+    if (opts && opts->fold_wait_event) {   // a deferred parameter update (as_opts) must land before the heads' weights are folded
+        const hipError_t e = hipStreamWaitEvent(sd ? sd->side : st, (hipEvent_t)opts->fold_wait_event, 0);
+        AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_fwd: cannot wait for fold_wait_event: %s", hipGetErrorString(e));
+    }
     if (sd) {
         AS_TRY(fork_to(st, sd->side, sd->fork[0]));
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->side));
@@ -579,6 +608,18 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     return head_fwd_impl(*d, L, P, ws + w.lin, R, out, ws + w.head, st);
 }
 
+extern "C" int as_artspeech_dw2(const as_dims* d, const float* P, int32_t B, int32_t T, float* G, float* ws, void* stream) {
+    AS_TRY(check_dims(d, "as_artspeech_dw2"));
+    AS_REQUIRE(!d->simple && P && G && ws && B > 0 && T > 0, AS_ERR_BAD_ARG, "as_artspeech_dw2: bad argument");
+    as_layout L;
+    AS_TRY(as_artspeech_layout(d, &L));
+    const ModelWs w = model_ws(*d, B, T);
+    const HeadWs hw = head_ws(*d, (int64_t)B * T);
+    float* hws = ws + w.head;
+    // beside a forward recurrence (2 B workgroups): 192 CUs to count on
+    return head_bwd_dw(*d, L, P, (int64_t)B * T, G, hws, hws + hw.slab2, (hipStream_t)stream, nullptr, 192, SLAB2_FLOATS, nullptr, 2, 2);
+}
+
 extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t* tokens, int64_t tok_stride,
                                 const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout, float* G,
                                 float* ws, const as_opts* opts, void* stream) {
@@ -602,6 +643,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     const bool presig = opts && opts->dout_presigmoid;
     const float* dpre3 = presig ? dout : nullptr;
     AS_TRY(head_bwd_dx(*d, L, P, out, dout, R, dzlin, ws + w.lin, hws, st, presig));
+    AS_REQUIRE(!(d->simple && opts && opts->defer_dw2), AS_ERR_UNSUPPORTED, "as_artspeech_bwd: defer_dw2 is for the GRU model");
     if (d->simple) {
         AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, slab, st, dpre3));
         AS_TRY(record_heads_done(st, st));
@@ -631,8 +673,14 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
     const int side_cus = sd ? 192 : 0;  // the recurrence's 2 * B workgroups hold 64 CUs while the side stream works
     const TrunkJob trunk{dzlin, ws + w.y1, G + L.lin_w, G + L.lin_b, H};
-    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus, sd ? SLAB2_FLOATS : SLAB_FLOATS, &trunk));
-    AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
+    // with a side stream: layers 3, 1 and the trunk now, layer 2 + unfold beside the layer-0 recurrence (see head_bwd_dw)
+    static const bool dw_one = AS_DIAG_SET("AS_HEAD_DW_ONE");   // ablation: everything in one launch here
+    const bool defer = opts && opts->defer_dw2;                  // layer 2's is computed later by as_artspeech_dw2()
+    const bool two_parts = (sd != nullptr && !dw_one) || defer;
+    AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus, sd ? SLAB2_FLOATS : SLAB_FLOATS, &trunk, two_parts ? 1 : 0,
+                       defer ? 5 : -1));
+    // [lin_w, total) of the flat gradient buffer is final from here on ([lin_w, ln2_g) with defer_dw2)
+    if (!two_parts || defer) AS_TRY(record_heads_done(st, s2));
     {
         // input gradient of GRU layer 1: [R][6H] . [6H][2H].  (diagnostic build, AS_DX1_LIN: the LDS-DMA kernel of the head
         // layers on 32-row x 256-column tiles instead of the general kernel's 64 x 64 tiles + in-kernel split-K)
@@ -667,6 +715,10 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_REQUIRE(rc == 1, rc < 0 ? rc : AS_ERR_UNSUPPORTED, "gru.bwd_l0: launch failed");
     } else {
         AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
+    }
+    if (two_parts && !defer) {
+        AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus, sd ? SLAB2_FLOATS : SLAB_FLOATS, nullptr, 2));
+        AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
     }
     AS_STEP("grub.dw_ih1", s2, gemm_tn(ws + w.dgi1, 6 * H, pdrop > 0.f ? ws + w.y0d : ws + w.y0, 2 * H, G + L.w_ih[1], 2 * H, 6 * H, 2 * H, R, s2, sl2, G + L.b_ih[1], 0));
     // dW_hh = dgh^T . h_{prev}: y shifted by -1 (forward) / +1 (reverse) frame; both directions as one batch of two

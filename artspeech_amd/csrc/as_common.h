@@ -77,6 +77,9 @@ __device__ __forceinline__ double as_wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// ReLU that keeps a NaN a NaN, like torch.relu (fmaxf(NaN, 0) = 0 would hide an invalid activation: the transformer's test
+// loop finds utterances with NaN predictions by exactly that propagation, transformer/evaluation.py:69-86)
+__device__ __forceinline__ float as_relu(float v) { return v < 0.f ? 0.f : v; }
 // v_exp_f32 + v_rcp_f32 (1 ulp each): |abs err| ~ 1e-7, far inside the 1e-4 parity budget, and 3x fewer
 // instructions than an IEEE division on the recurrence's critical path
 __device__ __forceinline__ float as_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 float v = acc[i][j][r] + bj;
-                                if (g.act == 1) v = fmaxf(v, 0.f);
+                                if (g.act == 1) v = as_relu(v);
                                 else if (g.act == 2) v = as_sigmoid(v);
                                 else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                                 c0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32] = v;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
                             const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                             if (row >= g.M) continue;
                             float v = acc[i][j][r] + bj;
-                            if (g.act == 1) v = fmaxf(v, 0.f);
+                            if (g.act == 1) v = as_relu(v);
                             else if (g.act == 2) v = as_sigmoid(v);
                             else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                             float* c = C + (long)row * g.ldc + col;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(GemmK g) {
                     const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                     if (!whole && m0 + wm * WM + 4 * lh + rr >= g.M) continue;
                     float v = acc[i][j][r] + bj;
-                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    if (g.act == 1) v = as_relu(v);
                     else if (g.act == 2) v = as_sigmoid(v);
                     else if (g.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     float* c = c0 + (long)rr * g.ldc + j * 32;

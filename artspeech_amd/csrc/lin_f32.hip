@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
                     const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (i < tm_eff && row < g.M) {   // (a 32-row tile owns only its first row block)
                         float v = acc[i][r] + bj;
-                        if (g.act == 1) v = fmaxf(v, 0.f);
+                        if (g.act == 1) v = as_relu(v);
                         else if (g.act == 2) v = as_sigmoid(v);
                         c0[(long)row * g.ldc] = v;
                     }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[i][r] + bj;
-            if (EPI == EPI_LNF) v = fmaxf(v, 0.f);
+            if (EPI == EPI_LNF) v = as_relu(v);
             smem[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = v;
         }
         lds_barrier();

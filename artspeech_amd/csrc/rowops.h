@@ -15,7 +15,7 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
 // the three layers of a head stack in one launch (index 0..2 = any order)
 int as_unfold3(const float* const dWf[3], const float* const dbf[3], const float* const W[3], const float* const gamma[3],
                const float* const beta[3], float* const dW[3], float* const dgamma[3], float* const dbeta[3], const int R[3],
-               const int K[3], int heads, hipStream_t st);
+               const int K[3], int heads, hipStream_t st, int count = 3);   // the first `count` (1..3) entries
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
                     hipStream_t st, float* scratch = nullptr, long scratch_floats = 0);
 // dW [C][E] = dtab^T . emb, db [C] = column sums of dtab, demb [V][E] = dtab . W   (dtab [V][C], emb [V][E], W [C][E])

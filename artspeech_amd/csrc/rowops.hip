@@ -726,14 +726,14 @@ int as_unfold(const float* dWf, const float* dbf, const float* W, const float* g
 }
 int as_unfold3(const float* const dWf[3], const float* const dbf[3], const float* const W[3], const float* const gamma[3],
                const float* const beta[3], float* const dW[3], float* const dgamma[3], float* const dbeta[3], const int R[3],
-               const int K[3], int heads, hipStream_t st) {
-    UnfoldJobs jobs;
+               const int K[3], int heads, hipStream_t st, int count) {
+    UnfoldJobs jobs{};
     int kmax = 0;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < count; ++i) {
         jobs.j[i] = UnfoldJob{dWf[i], dbf[i], W[i], gamma[i], beta[i], dW[i], dgamma[i], dbeta[i], R[i], K[i]};
         kmax = K[i] > kmax ? K[i] : kmax;
     }
-    hipLaunchKernelGGL(unfold3_kernel, dim3(as_cdiv(kmax, 64), heads, 3), dim3(1024), 0, st, jobs);
+    hipLaunchKernelGGL(unfold3_kernel, dim3(as_cdiv(kmax, 64), heads, count), dim3(1024), 0, st, jobs);
     AS_LAUNCH_CHECK("unfold3");
     return 0;
 }

@@ -6,6 +6,15 @@ This is the host side of ``run_epoch``'s per-batch body (reference train_phoneme
 is allocated once for a (B, T) shape, so a step is five library calls and no allocation -- suitable for
 HIP-graph capture.  The drop-in ``nn.Module`` / autograd path (models.py, metrics.py) runs the very
 same kernels and is what the parity tests use; this engine is what the benchmark and the DP trainer use.
+
+Software pipelining (``pipeline=True``).  The forward recurrences keep 64 of the 256 CUs busy for ~200 us with nothing
+beside them, while the backward has more weight-gradient GEMM work than fits beside ITS recurrences.  So the weight
+gradient of the heads' second Linear (9.2 GFLOP, its slab reduce and LayerNorm unfold), that slice's all-reduce and its
+Adam update are issued one step late, on a side stream beside the NEXT step's forward recurrences; the forward folds the
+head weights only after that update has landed (``as_opts.fold_wait_event``).  Every parameter still receives exactly the
+update of the unpipelined loop -- same gradients, same step count, same order of operations per element -- so the
+parameters after ``flush()`` are bit-identical; only the schedule differs.  ``flush()`` applies the pending slice at once
+(call it before reading parameters, checkpointing, or evaluating).
 """
 import ctypes as C
 import os
@@ -17,7 +26,7 @@ from . import _lib
 
 class TrainStep:
     def __init__(self, model, B, T, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None,
-                 optimizer=True):
+                 optimizer=True, pipeline=False):
         self.model = model
         self.dims = model.dims
         self.B, self.T = B, T
@@ -31,7 +40,13 @@ class TrainStep:
         # (RCCL only: gloo's asynchronous path on device tensors is pathologically slow -- rehearsals use one all-reduce)
         self.ar_overlap = (self.use_dist and os.environ.get("ARTSPEECH_NO_AR_OVERLAP") is None
                            and torch.distributed.get_backend(process_group) == "nccl")
-        self.head_off = int(_lib.layout(self.dims).lin_w)
+        lay = _lib.layout(self.dims)
+        self.head_off = int(lay.lin_w)
+        # pipelined mode: [late_off, total) = {ln2_g, ln2_b, w2, b2}, the last group of the flat layout, is produced and
+        # applied one step late (module docstring); needs the optimizer to be this engine's Adam and the GRU model
+        self.pipeline = bool(pipeline) and optimizer and not self.dims.simple
+        self.late_off = int(lay.ln2_g)
+        self.pending = None      # Adam step number of the slice that is still to be applied
         self.comm_stream = torch.cuda.Stream(device=model.flat.device) if self.ar_overlap else None
         L = _lib.lib()
         dev = model.flat.device
@@ -46,7 +61,11 @@ class TrainStep:
         self.exp_avg = torch.zeros_like(self.grads)
         self.exp_avg_sq = torch.zeros_like(self.grads)
         self.steps = 0
-        self.bwd_opts = _lib.Opts(0.0, 0, 1)
+        self.bwd_opts = _lib.Opts(0.0, 0, 1, 1 if self.pipeline else 0, None)
+        if self.pipeline:
+            self.late_stream = torch.cuda.Stream(device=dev)
+            self.late_event = torch.cuda.Event()
+            self.fwd_opts = _lib.Opts(0.0, 0, 0, 0, None)
 
     def forward_backward(self, tokens, lengths_dev, targets, loss_scale):
         """tokens (B, >=T) int64, lengths_dev (B,) int32 on device, targets (B, >=T, A, 2, N).
@@ -54,8 +73,16 @@ class TrainStep:
         L, d, st = _lib.lib(), self.dims, _lib.stream_ptr()
         P = self.model.flat.data
         B, T = self.B, self.T
+        fwd_opts = None
+        if self.pipeline and self.pending is not None:
+            # the previous step's late slice: weight gradient -> all-reduce -> Adam on the side stream, beside this step's
+            # forward recurrences; the forward's fold of the head weights waits for late_event, the recurrences do not
+            self._late_update(self.late_stream)
+            self.late_event.record(self.late_stream)
+            self.fwd_opts.fold_wait_event = self.late_event.cuda_event
+            fwd_opts = C.byref(self.fwd_opts)
         _lib.check(L.as_artspeech_fwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
-                                      B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, None, st), "as_artspeech_fwd")
+                                      B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, fwd_opts, st), "as_artspeech_fwd")
         # criterion backward and the model's final sigmoid backward in one pass: dout holds d(loss)/d(pre-sigmoid)
         _lib.check(L.as_euclid_masked_fwd_bwd_presigmoid(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1],
                                                          _lib.ptr(lengths_dev), B, T, d.n_art, d.n_samp, float(loss_scale),
@@ -64,6 +91,28 @@ class TrainStep:
         _lib.check(L.as_artspeech_bwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.dout), _lib.ptr(self.grads), _lib.ptr(self.ws),
                                       C.byref(self.bwd_opts), st), "as_artspeech_bwd")
+
+    def _late_update(self, stream):
+        """Weight gradient of the heads' second Linear of the step recorded in ``pending`` + its all-reduce + its Adam update,
+        enqueued on `stream` after everything the current stream holds (the backward that produced its operands)."""
+        L, d = _lib.lib(), self.dims
+        P, sp = self.model.flat.data, C.c_void_p(stream.cuda_stream)
+        stream.wait_stream(torch.cuda.current_stream())
+        _lib.check(L.as_artspeech_dw2(C.byref(d), _lib.ptr(P), self.B, self.T, _lib.ptr(self.grads), _lib.ptr(self.ws), sp),
+                   "as_artspeech_dw2")
+        lo, n = self.late_off, self.grads.numel() - self.late_off
+        if self.use_dist:
+            with torch.cuda.stream(stream):
+                torch.distributed.all_reduce(self.grads[lo:], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        _lib.check(L.as_adam_step(_lib.ptr(P[lo:]), _lib.ptr(self.grads[lo:]), _lib.ptr(self.exp_avg[lo:]),
+                                  _lib.ptr(self.exp_avg_sq[lo:]), n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                  self.weight_decay, self.pending, 1.0, sp), "as_adam_step")
+        self.pending = None
+
+    def flush(self):
+        """Apply the pending late slice now, on the current stream (no-op when nothing is pending)."""
+        if self.pipeline and self.pending is not None:
+            self._late_update(torch.cuda.current_stream())
 
     def bad_tokens(self):
         """Number of token ids outside [0, V) in the last batch (device word written by as_artspeech_fwd; the kernels clamp
@@ -87,12 +136,13 @@ class TrainStep:
         if not self.use_dist:
             return
         dist = torch.distributed
+        end = self.late_off if self.pipeline else self.grads.numel()   # pipelined: [late_off, total) follows one step late
         if not self.ar_overlap:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(self.grads[:end], op=dist.ReduceOp.SUM, group=self.pg)
             return
         _lib.check(_lib.lib().as_artspeech_wait_head_grads(_lib.stream_ptr(), self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
         with torch.cuda.stream(self.comm_stream):
-            tail = dist.all_reduce(self.grads[self.head_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            tail = dist.all_reduce(self.grads[self.head_off:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         head = dist.all_reduce(self.grads[:self.head_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         tail.wait()
         head.wait()
@@ -101,9 +151,12 @@ class TrainStep:
     def adam(self):
         L = _lib.lib()
         self.steps += 1
+        n = self.late_off if self.pipeline else self.grads.numel()   # pipelined: the late slice is updated by _late_update
         _lib.check(L.as_adam_step(_lib.ptr(self.model.flat.data), _lib.ptr(self.grads), _lib.ptr(self.exp_avg),
-                                  _lib.ptr(self.exp_avg_sq), self.grads.numel(), self.lr, self.betas[0], self.betas[1],
+                                  _lib.ptr(self.exp_avg_sq), n, self.lr, self.betas[0], self.betas[1],
                                   self.eps, self.weight_decay, self.steps, 1.0, _lib.stream_ptr()), "as_adam_step")
+        if self.pipeline:
+            self.pending = self.steps
 
     def step(self, tokens, lengths_dev, targets, loss_scale):
         self.forward_backward(tokens, lengths_dev, targets, loss_scale)

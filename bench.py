@@ -64,6 +64,7 @@ def gemm_flops(rows):
         "gru.table0": 2 * V * 6 * H * E, "grub.dw_ih0": 2 * V * 6 * H * E, "grub.demb": 2 * V * 6 * H * E,
         # the head layers' and the trunk's weight gradients as ONE multi-problem launch (wgrad_f32.hip, as_wgrad_multi)
         "headb.dw_fused": 2 * rows * A * 2 * N * D + 2 * rows * A * D * D + 2 * rows * A * D * H + 2 * rows * H * 2 * H,
+        "headb.dw31": 2 * rows * A * 2 * N * D + 2 * rows * A * D * H + 2 * rows * H * 2 * H,   # layers 3, 1 + trunk in one launch
     }
 
 
@@ -75,7 +76,7 @@ GEMM_FAMILIES = {
     "input gradients (C = A.B): lin_f32_kernel<64, false, 2> [head dx 3, 2 + LayerNorm/ReLU backward] + gemm_f32_kernel<*, *, true, false, true>":
         ["headb.dx3", "headb.dx2", "headb.dx1", "trunkb.dx", "grub.dx1", "grub.demb"],
     "weight gradients (C = A^T.B): wgrad_f32_kernel<*, 32> [heads] + gemm_f32_kernel<64, 64, false, false, true> [GRU, trunk]":
-        ["headb.dw_fused", "headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
+        ["headb.dw_fused", "headb.dw31", "headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
 }
 
 
@@ -215,6 +216,8 @@ def main():
                     help="which run is the headline `value` (N > 1 measures both)")
     ap.add_argument("--per-gpu-batch", type=int, default=B,
                     help="N = 1 only: utterances in the batch (default 32); b < 32 = one rank's share of a strong-scaling run")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="every step self-contained (no weight-gradient work carried into the next step's forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] measurements (N = 1)")
@@ -277,14 +280,20 @@ def main():
         tokens, targets = tokens.contiguous().to(dev), targets.contiguous().to(dev)
         lengths_dev = lengths.to(torch.int32).to(dev)
         scale = loss_scale(n_valid_global, A, N)
-        step = TrainStep(model, b_local, T, lr=1e-4, weight_decay=1e-6)
+        # pipeline: the weight gradient / Adam update of the heads' second Linear of step i runs beside the forward
+        # recurrences of step i + 1 (artspeech_amd/engine.py).  flush() applies what is pending: after it the parameters are
+        # those of the unpipelined loop, bit for bit.  The timed region starts flushed and ends flushed: it holds the whole
+        # work of exactly K steps.
+        step = TrainStep(model, b_local, T, lr=1e-4, weight_decay=1e-6, pipeline=not args.no_pipeline)
         log(f"rank {rank}/{world} [{mode}]: B={b_local} per rank, warm-up {args.warmup} steps ...")
         for _ in range(args.warmup):
             step.step(tokens, lengths_dev, targets, scale)
+        step.flush()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step.step(tokens, lengths_dev, targets, scale)
+        step.flush()
         barrier()
         elapsed = time.perf_counter() - t0
         loss_t = step.loss.detach().clone().reshape(1)
@@ -323,8 +332,9 @@ def main():
         psteps = min(args.steps, 20)
         L.as_profile_reset()  # same configuration as the timed region (side-stream overlap on)
         L.as_profile_enable(1)
-        for i in range(psteps):
-            step.forward_backward(tokens, lengths_dev, targets, scale)
+        for i in range(psteps):   # whole steps: the pipelined schedule carries work across the step boundary
+            step.step(tokens, lengths_dev, targets, scale)
+        step.flush()
         torch.cuda.synchronize()
         L.as_profile_enable(0)
         buf = C.create_string_buffer(1 << 16)
@@ -435,7 +445,9 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"encoder_decoder BiGRU (ArtSpeech) V=45 E=64 H=128, 11 articulators x 50 pts, T=200, "
                                    f"B={head['per_gpu_batch']} per GPU ({args.scaling} scaling), all lengths 200; step = fwd + "
-                                   "masked Euclidean loss + bwd + flat grad all-reduce + Adam",
+                                   "masked Euclidean loss + bwd + flat grad all-reduce + Adam" + ("" if args.no_pipeline else
+                                   "; software-pipelined across the step boundary (one weight gradient + its Adam slice run beside the "
+                                   "next step's forward recurrences; flushed inside the timed region)"),
                        "global_batch": head["global_batch"], "seq_len": T, "parallelism": f"dp{world}"},
             "loss": head["loss"],
             # ranks that exchanged gradients over RCCL (0 in a gloo rehearsal, where no RCCL communicator exists)

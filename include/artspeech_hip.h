@@ -60,8 +60,8 @@ typedef struct as_layout {
     /* heads, stacked over the A predictors (predictors.{a}.*): */
     int64_t ln1_g, ln1_b;     /* linear.0.{weight,bias}  [A][H] */
     int64_t w1, b1;           /* linear.1                [A][256][H], [A][256] */
-    int64_t ln2_g, ln2_b;     /* linear.3                [A][256] */
-    int64_t w2, b2;           /* linear.4                [A][256][256], [A][256] */
+    int64_t ln2_g, ln2_b;     /* linear.3                [A][256]   -- the group {ln2_g, ln2_b, w2, b2} is the LAST one of */
+    int64_t w2, b2;           /* linear.4                [A][256][256], [A][256]   the buffer: [ln2_g, total) (see as_opts) */
     int64_t ln3_g, ln3_b;     /* linear.6                [A][256] */
     int64_t w3, b3;           /* x_coords then y_coords  [A][2][N][256], [A][2][N] */
     int64_t total;            /* number of floats in the flat buffer (multiple of 64) */
@@ -91,6 +91,16 @@ typedef struct as_opts {
     /* as_artspeech_bwd only: non-zero => `dout` already holds the gradient w.r.t. the PRE-sigmoid activations (written by
        as_euclid_masked_fwd_bwd_presigmoid), so the separate dout * out * (1 - out) pass over the contours is skipped. */
     int32_t dout_presigmoid;
+    /* Software pipelining of the training loop across the step boundary (ArtSpeech only; artspeech_amd/engine.py):
+       as_artspeech_bwd with defer_dw2 != 0 leaves out the weight gradient of the heads' SECOND Linear (9.2 of the step's
+       22.9 GFLOP of weight gradients: grads [ln2_g, total) = the LAST group of the flat layout stays unwritten) and
+       as_artspeech_dw2() computes it later from the same workspace -- the engine runs it on a side stream beside the NEXT
+       step's forward recurrences (64 of 256 CUs busy), followed by that slice's all-reduce and Adam update.
+       as_artspeech_fwd with fold_wait_event != NULL (a hipEvent_t) makes the stream that folds the head weights wait for
+       that event first (the deferred update must be in place before the heads read their parameters); the recurrences do
+       not wait.  Same arithmetic on the same operands as the unpipelined step: bit-identical parameters. */
+    int32_t defer_dw2;
+    void* fold_wait_event;
 } as_opts;
 
 /* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96).
@@ -109,6 +119,11 @@ int as_artspeech_fwd(const as_dims* dims, const float* params, const int64_t* to
 int as_artspeech_bwd(const as_dims* dims, const float* params, const int64_t* tokens, int64_t tok_stride,
                      const int32_t* lengths, int32_t B, int32_t T, const float* out, const float* dout,
                      float* grads, float* ws, const as_opts* opts, void* stream);
+
+/* The part of the backward that as_artspeech_bwd(opts->defer_dw2) left out: weight / bias gradient of the heads' second Linear
+ * and of the LayerNorm in front of it -> grads [ln2_g, total).  Reads what forward + backward left in `ws` (valid until the
+ * next as_artspeech_fwd on that workspace reaches its heads, i.e. until that call's fold_wait_event is signalled). */
+int as_artspeech_dw2(const as_dims* dims, const float* params, int32_t B, int32_t T, float* grads, float* ws, void* stream);
 
 /* as_artspeech_bwd runs the weight-gradient GEMMs on a library-owned side stream beside the GRU backward
  * recurrences (fork/join by stream-ordered events; `stream` observes completion of everything on return

@@ -432,3 +432,47 @@ def test_out_of_range_token_ids_raise_like_nn_embedding(dev, bad):
         step.loss_value()
     step.step(x.to(dev), ld, tgt.to(dev), scale)   # the count is per batch, not sticky
     assert np.isfinite(step.loss_value())
+
+
+def test_pipelined_engine_is_bit_identical_to_the_unpipelined_one(dev):
+    """TrainStep(pipeline=True) carries the weight gradient + Adam update of the heads' second Linear into the next step's
+    forward (beside its recurrences).  After flush() the parameters, both Adam moments and every step's loss must equal the
+    unpipelined engine's BIT FOR BIT: same operands, same arithmetic, another schedule.  B*T is a multiple of 32 and >= 512 so
+    that the fused weight-gradient launches are the ones exercised; ragged lengths; batches change from step to step."""
+    from artspeech_amd.engine import TrainStep
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    V, A, B, T = 45, 3, 8, 96
+    lengths = torch.tensor([96, 90, 77, 64, 40, 33, 8, 1], dtype=torch.int32)
+    scale = 1.0 / (float(lengths.sum()) * A * 50)
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for _ in range(5):
+        x = torch.randint(1, V, (B, T), generator=g)
+        tgt = torch.rand(B, T, A, 2, 50, generator=g)
+        for b, l in enumerate(lengths):
+            x[b, l:] = 0
+            tgt[b, l:] = 0
+        batches.append((x.to(dev), tgt.to(dev)))
+    ld = lengths.to(dev)
+    results = []
+    for pipeline in (False, True):
+        torch.manual_seed(11)
+        model = ArtSpeech(V, A).to(dev)
+        step = TrainStep(model, B, T, lr=1e-3, weight_decay=1e-6, pipeline=pipeline)
+        assert step.pipeline == pipeline
+        losses = []
+        for x, tgt in batches:
+            step.step(x, ld, tgt, scale)
+            losses.append(step.loss.clone())
+        if pipeline:
+            assert step.pending is not None
+            # before the flush the late slice still holds the previous step's parameters
+            assert not torch.equal(model.flat.data[step.late_off:], results[0][0][step.late_off:])
+            assert torch.equal(model.flat.data[:step.late_off], results[0][0][:step.late_off])
+        step.flush()
+        torch.cuda.synchronize()
+        assert step.pending is None
+        results.append((model.flat.data.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone(), torch.stack(losses)))
+    for a, b, what in zip(results[0], results[1], ("parameters", "exp_avg", "exp_avg_sq", "losses")):
+        assert torch.equal(a, b), f"pipelined {what} differ: max |diff| {(a - b).abs().max().item():.3e}"
+    assert torch.isfinite(results[0][3]).all() and results[0][3][-1] < results[0][3][0]
