@@ -508,8 +508,10 @@ def test_full_width_model_matches_reference_fixture(dev):
     print(f"full-width transformer contours: worst |got - ref| / (1e-4 |ref| + 2e-6) = {worst_valid:.2f} on valid frames, "
           f"{worst_pad:.2f} on padded frames")
     assert worst_valid <= 1.0, worst_valid      # north_star: 1e-4 relative on contour coordinates
-    # frames past the utterance's end enter neither the loss nor any metric (train_..._transformer.py:113-118)
-    assert worst_pad <= 3.0, worst_pad
+    # frames past the utterance's end enter neither the loss nor any metric (train_..._transformer.py:113-118); there the
+    # reference differs from ITSELF (1 thread vs 8) by up to 0.52 of the bound (fixture: self_contour_ratio), this path from
+    # the reference by 1.11 (measured, round 3): held to 1.5 x the bound instead of the 3 x of round 2
+    assert worst_pad <= 1.5, worst_pad
     loss.backward()
     gv = model.named_grad_views()
     names = str(g["names"]).split("\n")
@@ -561,6 +563,20 @@ def test_full_width_model_matches_reference_fixture(dev):
         f = 2.0 if i == 3 else 1.5
         assert got_n[i] <= f * float(g["self_norm_q"][i]), (q[i], got_n[i], float(g["self_norm_q"][i]))
         assert got_s[i] <= f * float(g["self_slice_q"][i]), (q[i], got_s[i], float(g["self_slice_q"][i]))
+    # ... and BY DEPTH, against the reference's own per-tensor discrepancy of the same group (fixture: self_norm_err,
+    # self_slice_err): the heads and the output trunk have only their own three ReLUs between them and the loss, so their
+    # yardstick is ~500 x tighter than the decoder's (median slice error 1e-5 of max|g| instead of 5e-3); a wrong term there
+    # no longer hides behind the deep layers' noise.  Quantiles 50 / 90 % within 1.5 x, the group's worst tensor within 2.5 x
+    # (+ 5e-5: fp32 summation order on values that small).
+    self_n, self_s = g["self_norm_err"].astype(np.float64), g["self_slice_err"].astype(np.float64)
+    for gname, idx in sorted(groups.items()):
+        if len(idx) < 4:
+            continue
+        idx = np.array(idx)
+        for what, ours, ref in (("norm", norm_err[idx], self_n[idx]), ("slice", slice_err[idx], self_s[idx])):
+            for qq, f in ((0.5, 1.5), (0.9, 1.5), (1.0, 2.5)):
+                a_, b_ = float(np.quantile(ours, qq)), float(np.quantile(ref, qq))
+                assert a_ <= f * b_ + 5e-5, (gname, what, qq, a_, b_)
 
 
 class _CapturedLoader:

@@ -12,7 +12,15 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    # a step ends with the first Adam launch after its loss kernel; the pipelined engine's second Adam launch (the late
+    # slice, inside the NEXT step's forward) and the final flush are not step boundaries
+    adam, seen_loss = [], False
+    for i, r in enumerate(rows):
+        if "euclid_masked_kernel" in r["Kernel_Name"]:
+            seen_loss = True
+        elif "adam_kernel" in r["Kernel_Name"] and seen_loss:
+            adam.append(i)
+            seen_loss = False
     a, b = adam[-2], adam[-1]
     t0 = int(rows[a]["End_Timestamp"])
     for r in rows[a + 1:b + 1]:
