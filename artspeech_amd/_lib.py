@@ -107,6 +107,7 @@ PROTOTYPES = {
     "as_gru_unidir_fwd": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "as_intersect_semipolar_grid": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
     "as_artspeech_wait_head_grads": (_I32, [_P, _P]),
+    "as_gather_pad_rows": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I32, _D, _P, _P]),
     "as_lin_debug_stamps": (None, [_P, _I64]),
     "as_gru_debug_stamps": (None, [_P]),
     "as_profile_enable": (None, [_I32]),

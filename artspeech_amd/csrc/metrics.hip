@@ -91,43 +91,48 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
 // lane j scans all u for v_j (column minima).  min over squared distances, sqrt once (monotone).
 constexpr int P2CP_MAXPTS = 256;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// min_j |p - q_j|^2 over the n points (qx, qy) in LDS (padded to a multiple of 4 with +inf coordinates): four points per
+// step from two broadcast ds_read_b128, the arithmetic on float pairs (v_pk_add / v_pk_mul: half the instructions of the
+// scalar form), v_min3 to fold two candidates at once.  The kernel lives on vector-instruction issue (50 x 50 pair
+// distances twice per 800-byte tile), not on HBM: ~3.5 instructions per pair instead of ~8.
+__device__ __forceinline__ float p2cp_scan(float px, float py, const float* __restrict__ qx, const float* __restrict__ qy, int n4) {
+    const f32x2 px2 = {px, px}, py2 = {py, py};
+    float m = INFINITY;
+    for (int j = 0; j < n4; j += 4) {
+        const float4 x4 = *reinterpret_cast<const float4*>(qx + j), y4 = *reinterpret_cast<const float4*>(qy + j);
+        const f32x2 dxa = px2 - f32x2{x4.x, x4.y}, dxb = px2 - f32x2{x4.z, x4.w};
+        const f32x2 dya = py2 - f32x2{y4.x, y4.y}, dyb = py2 - f32x2{y4.z, y4.w};
+        const f32x2 sa = dxa * dxa + dya * dya, sb = dxb * dxb + dyb * dyb;
+        m = fminf(fminf(m, sa.x), sa.y);
+        m = fminf(fminf(m, sb.x), sb.y);
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void p2cp_kernel(const float* __restrict__ u, long u_tile, long u_pt, long u_xy, int nu,
                                                    const float* __restrict__ v, long v_tile, long v_pt, long v_xy, int nv,
                                                    long tiles, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + wave;
-    float* ux = smem + (long)wave * 2 * (nu + nv);
-    float* uy = ux + nu;
-    float* vx = uy + nu;
-    float* vy = vx + nv;
+    const int nu4 = (nu + 3) & ~3, nv4 = (nv + 3) & ~3;   // padded with +inf: a padding point is never a minimum
+    float* ux = smem + (long)wave * 2 * (nu4 + nv4);
+    float* uy = ux + nu4;
+    float* vx = uy + nu4;
+    float* vy = vx + nv4;
     if (tile < tiles) {
         const float* up = u + tile * u_tile;
         const float* vp = v + tile * v_tile;
-        for (int i = lane; i < nu; i += 64) { ux[i] = up[i * u_pt]; uy[i] = up[i * u_pt + u_xy]; }
-        for (int i = lane; i < nv; i += 64) { vx[i] = vp[i * v_pt]; vy[i] = vp[i * v_pt + v_xy]; }
+        for (int i = lane; i < nu4; i += 64) { ux[i] = i < nu ? up[i * u_pt] : INFINITY; uy[i] = i < nu ? up[i * u_pt + u_xy] : INFINITY; }
+        for (int i = lane; i < nv4; i += 64) { vx[i] = i < nv ? vp[i * v_pt] : INFINITY; vy[i] = i < nv ? vp[i * v_pt + v_xy] : INFINITY; }
     }
     __syncthreads();
     if (tile >= tiles) return;
     float su = 0.f, sv = 0.f;
-    for (int i = lane; i < nu; i += 64) {
-        const float px = ux[i], py = uy[i];
-        float m = INFINITY;
-        for (int j = 0; j < nv; ++j) {
-            const float dx = px - vx[j], dy = py - vy[j];
-            m = fminf(m, dx * dx + dy * dy);
-        }
-        su += sqrtf(m);
-    }
-    for (int j = lane; j < nv; j += 64) {
-        const float px = vx[j], py = vy[j];
-        float m = INFINITY;
-        for (int i = 0; i < nu; ++i) {
-            const float dx = ux[i] - px, dy = uy[i] - py;
-            m = fminf(m, dx * dx + dy * dy);
-        }
-        sv += sqrtf(m);
-    }
+    for (int i = lane; i < nu; i += 64) su += sqrtf(p2cp_scan(ux[i], uy[i], vx, vy, nv4));   // row minima
+    for (int j = lane; j < nv; j += 64) sv += sqrtf(p2cp_scan(vx[j], vy[j], ux, uy, nu4));   // column minima
     su = as_wave_sum(su);
     sv = as_wave_sum(sv);
     if (lane == 0) out[tile] = (su / nu + sv / nv) * 0.5f;
@@ -153,57 +158,85 @@ __global__ __launch_bounds__(256) void p2cp_utt_mean_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------- tract variables
-// one wave per (frame, variable).  Lane j owns arr2 point j and scans arr1 in order keeping the FIRST
-// minimum (strict <), exactly torch's min(dim=0); then the wave takes the first minimum over j.
-// Distances use un-contracted fp32 ops (mul, mul, add, sqrt) so that they are bit-identical to the
-// element-wise formula and the arg-min pairs are reproducible.
+// Correctly rounded fp32 square root from v_sqrt_f32 (1 ulp) + two fused residual tests against the neighbouring floats
+// (the sequence LLVM emits for an IEEE sqrtf on this target, written out so that it does not depend on compiler flags):
+// bit-identical to sqrtf on the host, which is what makes the arg-min pairs reproducible.  (Round 2 went through
+// v_sqrt_f64: ~3x the instructions.)  s >= 0, finite; tiny arguments are scaled out of the denormal range first.
+__device__ __forceinline__ float as_sqrt_rn(float s) {
+    const bool tiny = s < 0x1p-96f;
+    const float x = tiny ? s * 0x1p+32f : s;
+    float r = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(r) - 1), up = __int_as_float(__float_as_int(r) + 1);
+    const float vp = __builtin_fmaf(-dn, r, x), vs = __builtin_fmaf(-up, r, x);
+    r = vp <= 0.f ? dn : r;
+    r = vs > 0.f ? up : r;
+    r = tiny ? r * 0x1p-16f : r;
+    return (x == 0.f || x == INFINITY) ? x : r;
+}
+
+// One workgroup per FRAME, one wave per variable (LA, TTCD, TBCD, VEL: spec rows).  The articulator rows the four variables
+// slice are staged in LDS once per frame (coalesced 4-byte lanes over the (A, 2, N) rows), so every pair distance reads
+// broadcast LDS words instead of global memory.  Lane j owns arr2 point j and scans arr1 in order keeping the FIRST minimum
+// (strict <), exactly torch's min(dim=0); then the wave takes the first minimum over j.  Distances use un-contracted fp32
+// ops (sub, mul, mul, add, correctly rounded sqrt): bit-identical to the element-wise formula on the host.
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ contours, long frames, int A, int N,
                                                  const int* __restrict__ spec, int n_tv, float* __restrict__ values,
                                                  float* __restrict__ poc1, float* __restrict__ poc2, int* __restrict__ idx) {
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (item >= frames * n_tv) return;
-    const long f = item / n_tv;
-    const int v = (int)(item - f * n_tv);
-    const int* sp = spec + v * 9;
+    extern __shared__ __attribute__((aligned(16))) float fr_s[];   // [A][2][N]: the whole frame (2.2 KB at A = 11)
+    const long f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* fr = contours + f * (long)A * 2 * N;
-    const int c1 = sp[0], s1 = sp[1], n1 = sp[2] - sp[1];
-    const int c2a = sp[3], s2a = sp[4], n2a = sp[5] - sp[4];
-    const int c2b = sp[6], s2b = sp[7], n2b = c2b >= 0 ? sp[8] - sp[7] : 0;
-    const int n2 = n2a + n2b;
-    const float* x1 = fr + (long)c1 * 2 * N + s1;
-    float best = INFINITY;
-    int bi = 0, bj = 0x7fffffff;
-    float bx2 = 0.f, by2 = 0.f;
-    for (int j = lane; j < n2; j += 64) {
-        const float* p2 = j < n2a ? fr + (long)c2a * 2 * N + s2a + j : fr + (long)c2b * 2 * N + s2b + (j - n2a);
-        const float qx = p2[0], qy = p2[N];
-        float m = INFINITY;
-        int mi = 0;
-        for (int i = 0; i < n1; ++i) {
-            const float dx = __fsub_rn(x1[i], qx), dy = __fsub_rn(x1[N + i], qy);
-            // correctly rounded fp32 sqrt via fp64 (v_sqrt_f32 alone is 1 ulp): 53 >= 2*24+2 bits, so the
-            // double rounding is exact and d is bit-identical to an IEEE sqrtf on the host
-            const float d = (float)__dsqrt_rn((double)__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-            if (d < m) { m = d; mi = i; }
+    // only the articulators some variable slices (6 of 11 in the reference's configuration: 2.4 of 4.4 KB per frame)
+    unsigned need = 0;
+    for (int v = 0; v < n_tv; ++v)
+        for (int q = 0; q < 3; ++q) {
+            const int c = spec[v * 9 + 3 * q];
+            if (c >= 0 && c < 32) need |= 1u << c;
         }
-        if (m < best) { best = m; bi = mi; bj = j; bx2 = qx; by2 = qy; }  // j ascending per lane: first min kept
+    for (int i = threadIdx.x; i < A * 2 * N; i += 256) {
+        const int c = i / (2 * N);
+        if (c >= 32 || ((need >> c) & 1u)) fr_s[i] = fr[i];
     }
-    // wave arg-min with smallest-j tie break
+    __syncthreads();
+    for (int v = wave; v < n_tv; v += 4) {
+        const int* sp = spec + v * 9;
+        const int c1 = sp[0], s1 = sp[1], n1 = sp[2] - sp[1];
+        const int c2a = sp[3], s2a = sp[4], n2a = sp[5] - sp[4];
+        const int c2b = sp[6], s2b = sp[7], n2b = c2b >= 0 ? sp[8] - sp[7] : 0;
+        const int n2 = n2a + n2b;
+        const float* x1 = fr_s + c1 * 2 * N + s1;
+        float best = INFINITY;
+        int bi = 0, bj = 0x7fffffff;
+        float bx2 = 0.f, by2 = 0.f;
+        for (int j = lane; j < n2; j += 64) {
+            const float* p2 = j < n2a ? fr_s + c2a * 2 * N + s2a + j : fr_s + c2b * 2 * N + s2b + (j - n2a);
+            const float qx = p2[0], qy = p2[N];
+            float m = INFINITY;
+            int mi = 0;
+            for (int i = 0; i < n1; ++i) {
+                const float dx = __fsub_rn(x1[i], qx), dy = __fsub_rn(x1[N + i], qy);
+                const float d = as_sqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                if (d < m) { m = d; mi = i; }
+            }
+            if (m < best) { best = m; bi = mi; bj = j; bx2 = qx; by2 = qy; }  // j ascending per lane: first min kept
+        }
+        // wave arg-min with smallest-j tie break
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64), oj = __shfl_xor(bj, o, 64);
-        const float ox = __shfl_xor(bx2, o, 64), oy = __shfl_xor(by2, o, 64);
-        if (ob < best || (ob == best && oj < bj)) { best = ob; bi = oi; bj = oj; bx2 = ox; by2 = oy; }
-    }
-    if (lane == 0) {
-        values[item] = best;
-        poc1[item * 2] = x1[bi];
-        poc1[item * 2 + 1] = x1[N + bi];
-        poc2[item * 2] = bx2;
-        poc2[item * 2 + 1] = by2;
-        if (idx) { idx[item * 2] = bi; idx[item * 2 + 1] = bj; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64), oj = __shfl_xor(bj, o, 64);
+            const float ox = __shfl_xor(bx2, o, 64), oy = __shfl_xor(by2, o, 64);
+            if (ob < best || (ob == best && oj < bj)) { best = ob; bi = oi; bj = oj; bx2 = ox; by2 = oy; }
+        }
+        if (lane == 0) {
+            const long item = f * n_tv + v;
+            values[item] = best;
+            poc1[item * 2] = x1[bi];
+            poc1[item * 2 + 1] = x1[N + bi];
+            poc2[item * 2] = bx2;
+            poc2[item * 2 + 1] = by2;
+            if (idx) { idx[item * 2] = bi; idx[item * 2 + 1] = bj; }
+        }
     }
 }
 
@@ -253,14 +286,18 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
         if (i < n) mx[i] = seg[c];
     }
     __builtin_amdgcn_wave_barrier();
+    // the ordered running sum (lane 0, through LDS: its only dependent chain is the add), then every lane stores its share
+    // of the row: 100 single-lane 8-byte stores per frame had made this the longest part of the kernel
     if (lane == 0) {
         double d = 0.0;
-        dists[f * n] = 0.0;
+        my[0] = 0.0;
         for (int i = 1; i < n; ++i) {
             d = __dadd_rn(mx[i], d);
-            dists[f * n + i] = d;
+            my[i] = d;
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) dists[f * n + i] = my[i];
 }
 
 // ---------------------------------------------------------------- evenly spaced resampling of fx over x (fp64 in, fp32 out)
@@ -507,7 +544,7 @@ extern "C" int as_p2cp_fwd(const float* u, int64_t u_tile, int64_t u_pt, int64_t
     AS_REQUIRE(u && v && out && tiles > 0, AS_ERR_BAD_ARG, "as_p2cp_fwd: bad argument");
     AS_REQUIRE(n_u > 0 && n_v > 0 && n_u <= P2CP_MAXPTS && n_v <= P2CP_MAXPTS, AS_ERR_UNSUPPORTED,
                "as_p2cp_fwd: point counts %d, %d must be in [1, %d]", n_u, n_v, P2CP_MAXPTS);
-    const size_t shm = (size_t)4 * 2 * (n_u + n_v) * sizeof(float);
+    const size_t shm = (size_t)4 * 2 * (((n_u + 3) & ~3) + ((n_v + 3) & ~3)) * sizeof(float);
     hipLaunchKernelGGL(p2cp_kernel, dim3(as_cdiv(tiles, 4)), dim3(256), shm, (hipStream_t)stream, u, (long)u_tile, (long)u_pt,
                        (long)u_xy, n_u, v, (long)v_tile, (long)v_pt, (long)v_xy, n_v, (long)tiles, out);
     AS_LAUNCH_CHECK("as_p2cp_fwd");
@@ -536,7 +573,9 @@ extern "C" int as_tract_variables_fwd(const float* contours, int64_t frames, int
                                       int32_t n_tv, float* values, float* poc1, float* poc2, int32_t* idx, void* stream) {
     AS_REQUIRE(contours && spec && values && poc1 && poc2 && frames > 0 && A > 0 && N > 0 && n_tv > 0, AS_ERR_BAD_ARG,
                "as_tract_variables_fwd: bad argument");
-    hipLaunchKernelGGL(tv_kernel, dim3(as_cdiv((long)frames * n_tv, 4)), dim3(256), 0, (hipStream_t)stream, contours,
+    const size_t shm = (size_t)A * 2 * N * sizeof(float);
+    AS_REQUIRE(shm <= 64 * 1024 && frames < (1LL << 31), AS_ERR_UNSUPPORTED, "as_tract_variables_fwd: frame of %d x 2 x %d floats", A, N);
+    hipLaunchKernelGGL(tv_kernel, dim3((unsigned)frames), dim3(256), shm, (hipStream_t)stream, contours,
                        (long)frames, A, N, spec, n_tv, values, poc1, poc2, idx);
     AS_LAUNCH_CHECK("as_tract_variables_fwd");
     return 0;

@@ -422,6 +422,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int c = threadIdx.x & 63; c < C; c += 64) out[m * C + c] = table[v * C + c];
 }
 
+// ---- batched collate on the device: out[b][t][:] = t < len[b] ? src[first[b] + t][:] : pad  (pad_sequence of a batch whose
+// unpadded utterances lie back to back in one resident buffer; dataset.py:27-65 of the reference does this on the host)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pad_kernel(const T* __restrict__ src, const long* __restrict__ first,
+                                                         const int* __restrict__ len, int Tmax, long row_elems, T pad,
+                                                         T* __restrict__ out, long total) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long row = i / row_elems, e = i - row * row_elems;
+        const long b = row / Tmax;
+        const int t = (int)(row - b * Tmax);
+        out[i] = t < len[b] ? src[(first[b] + t) * row_elems + e] : pad;
+    }
+}
+
 // ---- *count = ids outside [0, V) (nn.Embedding raises for them; the kernels clamp, the host reads this word) ----------
 __global__ __launch_bounds__(1024) void count_bad_tokens_kernel(const int64_t* __restrict__ tokens, long tok_stride, int T, long rows,
                                                                 int V, int* __restrict__ count) {
@@ -891,6 +906,22 @@ extern "C" int as_unfold_ln(const float* dWf, const float* dbf, const float* W, 
 extern "C" int as_relu_bwd(const float* g, const float* act, float* dst, int64_t n, void* stream) {
     AS_REQUIRE(g && act && dst && n > 0, AS_ERR_BAD_ARG, "as_relu_bwd: bad argument");
     return as_relu_mask(g, act, dst, (long)n, (hipStream_t)stream);
+}
+
+extern "C" int as_gather_pad_rows(const void* src, const int64_t* first_row, const int32_t* lengths, int32_t B, int32_t T,
+                                  int64_t row_elems, int32_t elem_bytes, double pad_value, void* out, void* stream) {
+    AS_REQUIRE(src && first_row && lengths && out && B > 0 && T > 0 && row_elems > 0, AS_ERR_BAD_ARG, "as_gather_pad_rows: bad argument");
+    AS_REQUIRE(elem_bytes == 4 || elem_bytes == 8, AS_ERR_UNSUPPORTED, "as_gather_pad_rows: element size %d", elem_bytes);
+    const long total = (long)B * T * row_elems;
+    const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(gather_pad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, (const long*)first_row,
+                           lengths, T, (long)row_elems, (float)pad_value, (float*)out, total);
+    else   // int64 token ids
+        hipLaunchKernelGGL(gather_pad_kernel<long>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)src, (const long*)first_row,
+                           lengths, T, (long)row_elems, (long)pad_value, (long*)out, total);
+    AS_LAUNCH_CHECK("as_gather_pad_rows");
+    return 0;
 }
 
 extern "C" int as_embed_posenc(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pe, float* out,

@@ -407,6 +407,12 @@ int as_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                  void* stream);
 
+/* Batched collate on the device (pad_sequence_collate_fn, encoder_decoder/dataset.py:27-65, for a data set that is resident
+ * in HBM): utterance b's `lengths[b]` rows start at row `first_row[b]` of `src` ([rows][row_elems], 4-byte floats or 8-byte
+ * token ids); out [B][T][row_elems] = those rows followed by `pad_value` (0 for tokens / contours, -1 for voicing). */
+int as_gather_pad_rows(const void* src, const int64_t* first_row, const int32_t* lengths, int32_t B, int32_t T,
+                       int64_t row_elems, int32_t elem_bytes, double pad_value, void* out, void* stream);
+
 /* Optional per-kernel-phase timing with HIP events recorded on the launch stream (for bench.py's
  * roofline object).  as_profile_report writes "name count total_ms\n" lines (NUL terminated, truncated
  * to buflen) and returns the untruncated length; it waits for the recorded events to complete. */

@@ -551,6 +551,27 @@ def test_tract_variables_match_reference_fixture(dev):
     assert np.array_equal(tvs["LA"]["poc_1"].cpu().numpy(), g["poc1"][0, 0])
 
 
+def test_tract_variables_are_bit_exact_on_many_frames(dev):
+    """1500 random frames (11 articulators, some points exactly shared between the two sets, some coordinates tiny) against
+    the float32 oracle: values AND arg-min index pairs bit for bit.  Pins the correctly rounded fp32 square root the kernel
+    builds from v_sqrt_f32 + fused residual tests (a 1-ulp sqrt would merge or split distance ties)."""
+    from artspeech_amd.tract_variables import tract_variables_batched
+    arts = sorted(["arytenoid-cartilage", "epiglottis", "lower-incisor", "lower-lip", "pharynx", "soft-palate-midline",
+                   "thyroid-cartilage", "tongue", "upper-incisor", "upper-lip", "vocal-folds"])
+    rng = np.random.RandomState(5)
+    frames = rng.rand(1500, 11, 2, 50).astype(np.float32)
+    frames[::3] = np.round(frames[::3] * 64) / 64                     # a coarse grid: many exact distance ties
+    frames[1::5] *= np.float32(1e-22)                                   # squared distances in the fp32 denormal range
+    li, ul = arts.index("lower-lip"), arts.index("upper-lip")
+    frames[::4, ul, :, 7] = frames[::4, li, :, 30]                       # a shared point: distance exactly 0
+    values, poc1, poc2, idx = tract_variables_batched(T_(frames, dev), arts)
+    v, ix = values.cpu().numpy(), idx.cpu().numpy()
+    for f in range(0, 1500, 3):
+        ov, _, _, oi = O.tract_variables(frames[f], arts, dtype=np.float32)
+        assert np.array_equal(v[f], ov.astype(np.float32)), (f, v[f], ov)
+        assert np.array_equal(ix[f], oi), (f, ix[f], oi)
+
+
 def test_area_function_matches_reference_fixture(dev):
     from artspeech_amd.area_function import area_function, area_function_batched
     g = load_golden("area_function")

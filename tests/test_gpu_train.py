@@ -476,3 +476,34 @@ def test_pipelined_engine_is_bit_identical_to_the_unpipelined_one(dev):
     for a, b, what in zip(results[0], results[1], ("parameters", "exp_avg", "exp_avg_sq", "losses")):
         assert torch.equal(a, b), f"pipelined {what} differ: max |diff| {(a - b).abs().max().item():.3e}"
     assert torch.isfinite(results[0][3]).all() and results[0][3][-1] < results[0][3][0]
+
+
+def test_hbm_resident_dataset_collates_like_the_host_collate(dev):
+    """HBMResidentDataset.collate (device-side gather / pad, as_gather_pad_rows) returns the tuple of pad_sequence_collate_fn:
+    same order, dtypes, padding values (0 / -1), with the tensor fields on the device; run_epoch gives the same loss over it."""
+    import train_phoneme_to_articulation as tr
+    from torch.utils.data import DataLoader
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import (
+        HBMResidentDataset, SyntheticArtSpeechDataset, pad_sequence_collate_fn)
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance
+    from artspeech_amd.settings import VALID
+    voc = {"<blank>": 0, "<unk>": 1, **{f"p{i}": i + 2 for i in range(10)}}
+    ds = SyntheticArtSpeechDataset(21, voc, ARTS, n_samples=50, min_len=1, max_len=33, seed=4, voiced_tokens=["p1", "p4"])
+    rds = HBMResidentDataset(ds, dev)
+    assert len(rds) == len(ds) and rds.dataset_config is ds.dataset_config
+    for idx in ([3, 0, 7, 12, 20], [5], list(range(21))):
+        want = pad_sequence_collate_fn([ds[i] for i in idx])
+        got = rds.collate(idx)
+        assert got[0] == want[0] and got[4] == want[4] and got[6] == want[6]
+        assert torch.equal(got[3], want[3]) and got[3].dtype == want[3].dtype and not got[3].is_cuda
+        for f in (1, 2, 5, 7):
+            assert got[f].is_cuda and got[f].dtype == want[f].dtype and got[f].shape == want[f].shape
+            assert torch.equal(got[f].cpu(), want[f]), f
+    torch.manual_seed(0)
+    model = ArtSpeech(len(voc), len(ARTS)).to(dev)
+    crit = EuclideanDistance("none")
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    a = tr.run_epoch(VALID, 1, model, DataLoader(ds, batch_size=8, shuffle=False, collate_fn=pad_sequence_collate_fn), opt, crit, device=dev)
+    b = tr.run_epoch(VALID, 1, model, DataLoader(rds, batch_size=8, shuffle=False, collate_fn=rds.collate), opt, crit, device=dev)
+    assert a["loss"] == b["loss"]
