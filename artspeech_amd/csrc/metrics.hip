@@ -176,13 +176,23 @@ __device__ __forceinline__ float as_sqrt_rn(float s) {
 
 // One workgroup per FRAME, one wave per variable (LA, TTCD, TBCD, VEL: spec rows).  The articulator rows the four variables
 // slice are staged in LDS once per frame (coalesced 4-byte lanes over the (A, 2, N) rows), so every pair distance reads
-// broadcast LDS words instead of global memory.  Lane j owns arr2 point j and scans arr1 in order keeping the FIRST minimum
-// (strict <), exactly torch's min(dim=0); then the wave takes the first minimum over j.  Distances use un-contracted fp32
-// ops (sub, mul, mul, add, correctly rounded sqrt): bit-identical to the element-wise formula on the host.
+// broadcast LDS words instead of global memory.  Lane j owns arr2 point j and scans arr1; the result must be torch's
+// min(dim=0) of the DISTANCES: the first index whose correctly rounded sqrt(dx^2 + dy^2) is minimal.  The kernel lives on
+// vector-instruction issue (28 M pair distances per 6400 frames), so the scan is arranged for few instructions per pair:
+//   pass 1  minimum of the SQUARED distances, two arr1 points per step on float pairs (v_pk_add / v_pk_mul, v_min3): sqrt
+//           is monotone, so d_min = sqrt_rn(s_min) -- one square root per lane instead of one per pair;
+//   s_hi    the largest float whose correctly rounded root is still d_min (at most three floats share a root);
+//   pass 2  the first i with s_i <= s_hi: exactly the first index whose distance equals d_min, ties of distinct squared
+//           distances that round to the same root included.
+// Squared distances use un-contracted fp32 ops (sub, mul, mul, add), component for component what the scalar formula gives:
+// values and arg-min pairs are bit-identical to the element-wise evaluation on the host.  Then the wave takes the first
+// minimum over j.  (Round 2: one wave per (frame, variable), operands from global memory, a v_sqrt_f64 per pair.)
+constexpr int TV_MAXPTS = 64;   // points per slice (the reference's slices hold 15 .. 50)
+
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ contours, long frames, int A, int N,
                                                  const int* __restrict__ spec, int n_tv, float* __restrict__ values,
                                                  float* __restrict__ poc1, float* __restrict__ poc2, int* __restrict__ idx) {
-    extern __shared__ __attribute__((aligned(16))) float fr_s[];   // [A][2][N]: the whole frame (2.2 KB at A = 11)
+    extern __shared__ __attribute__((aligned(16))) float fr_s[];   // [A][2][N] the frame, then [4][2][TV_MAXPTS] arr1 copies
     const long f = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* fr = contours + f * (long)A * 2 * N;
@@ -198,6 +208,8 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ conto
         if (c >= 32 || ((need >> c) & 1u)) fr_s[i] = fr[i];
     }
     __syncthreads();
+    float* ax = fr_s + ((A * 2 * N + 3) & ~3) + wave * 2 * TV_MAXPTS;   // this wave's arr1, 8-byte aligned pairs, padded with +inf
+    float* ay = ax + TV_MAXPTS;
     for (int v = wave; v < n_tv; v += 4) {
         const int* sp = spec + v * 9;
         const int c1 = sp[0], s1 = sp[1], n1 = sp[2] - sp[1];
@@ -205,37 +217,62 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ conto
         const int c2b = sp[6], s2b = sp[7], n2b = c2b >= 0 ? sp[8] - sp[7] : 0;
         const int n2 = n2a + n2b;
         const float* x1 = fr_s + c1 * 2 * N + s1;
+        const int n1e = (n1 + 1) & ~1;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n1e) {
+            ax[lane] = lane < n1 ? x1[lane] : INFINITY;
+            ay[lane] = lane < n1 ? x1[N + lane] : INFINITY;
+        }
+        __builtin_amdgcn_wave_barrier();
         float best = INFINITY;
         int bi = 0, bj = 0x7fffffff;
         float bx2 = 0.f, by2 = 0.f;
         for (int j = lane; j < n2; j += 64) {
             const float* p2 = j < n2a ? fr_s + c2a * 2 * N + s2a + j : fr_s + c2b * 2 * N + s2b + (j - n2a);
             const float qx = p2[0], qy = p2[N];
-            float m = INFINITY;
+            const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy};
+            float smin = INFINITY;
+            for (int i = 0; i < n1e; i += 2) {
+                const f32x2 dx = *reinterpret_cast<const f32x2*>(ax + i) - qx2, dy = *reinterpret_cast<const f32x2*>(ay + i) - qy2;
+                const f32x2 sq = dx * dx + dy * dy;
+                smin = fminf(fminf(smin, sq.x), sq.y);
+            }
+            const float m = as_sqrt_rn(smin);
+            float s_hi = smin;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {   // at most three consecutive floats share a correctly rounded root
+                const float nxt = __int_as_float(__float_as_int(s_hi) + 1);
+                s_hi = (s_hi < INFINITY && as_sqrt_rn(nxt) == m) ? nxt : s_hi;
+            }
             int mi = 0;
-            for (int i = 0; i < n1; ++i) {
-                const float dx = __fsub_rn(x1[i], qx), dy = __fsub_rn(x1[N + i], qy);
-                const float d = as_sqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-                if (d < m) { m = d; mi = i; }
+            bool found = false;
+            for (int i = 0; i < n1e; i += 2) {
+                const f32x2 dx = *reinterpret_cast<const f32x2*>(ax + i) - qx2, dy = *reinterpret_cast<const f32x2*>(ay + i) - qy2;
+                const f32x2 sq = dx * dx + dy * dy;
+                const bool c0 = sq.x <= s_hi, c1b = sq.y <= s_hi;
+                mi = found ? mi : (c0 ? i : (c1b ? i + 1 : mi));
+                found = found || c0 || c1b;
             }
             if (m < best) { best = m; bi = mi; bj = j; bx2 = qx; by2 = qy; }  // j ascending per lane: first min kept
         }
-        // wave arg-min with smallest-j tie break
+        // wave arg-min with smallest-j tie break: (best, bj) travel, the winner's other fields are read out afterwards
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64), oj = __shfl_xor(bj, o, 64);
-            const float ox = __shfl_xor(bx2, o, 64), oy = __shfl_xor(by2, o, 64);
-            if (ob < best || (ob == best && oj < bj)) { best = ob; bi = oi; bj = oj; bx2 = ox; by2 = oy; }
+            const int oj = __shfl_xor(bj, o, 64);
+            if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
         }
+        const int wl = bj < 0x7fffffff ? (bj & 63) : 0;   // the lane that owns arr2 point bj
+        const int wbi = __shfl(bi, wl, 64);
+        const float wx = __shfl(bx2, wl, 64), wy = __shfl(by2, wl, 64);
         if (lane == 0) {
             const long item = f * n_tv + v;
             values[item] = best;
-            poc1[item * 2] = x1[bi];
-            poc1[item * 2 + 1] = x1[N + bi];
-            poc2[item * 2] = bx2;
-            poc2[item * 2 + 1] = by2;
-            if (idx) { idx[item * 2] = bi; idx[item * 2 + 1] = bj; }
+            poc1[item * 2] = x1[wbi];
+            poc1[item * 2 + 1] = x1[N + wbi];
+            poc2[item * 2] = wx;
+            poc2[item * 2 + 1] = wy;
+            if (idx) { idx[item * 2] = wbi; idx[item * 2 + 1] = bj; }
         }
     }
 }
@@ -259,17 +296,19 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
         for (int i = lane; i < n; i += 64) {
             const double ax = a[i * pt_stride], ay = a[i * pt_stride + xy_stride];
             const double bx = b[i * pt_stride], by = b[i * pt_stride + xy_stride];
-            mx[i] = __dadd_rn(fmin(ax, bx), __ddiv_rn(fabs(__dsub_rn(ax, bx)), 2.0));
-            my[i] = __dadd_rn(fmin(ay, by), __ddiv_rn(fabs(__dsub_rn(ay, by)), 2.0));
+            // (x / 2 as x * 0.5: a power-of-two scaling is exact either way, and an fp64 division is ~30 instructions --
+            // the kernel is bound by its fp64 instruction count, not by the 4.8 KB it moves per frame)
+            mx[i] = __dadd_rn(fmin(ax, bx), __dmul_rn(fabs(__dsub_rn(ax, bx)), 0.5));
+            my[i] = __dadd_rn(fmin(ay, by), __dmul_rn(fabs(__dsub_rn(ay, by)), 0.5));
             const double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by);
-            const double r = __ddiv_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), 2.0);
+            const double r = __dmul_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), 0.5);
             fx[f * n + i] = __dmul_rn(alpha, beta_is_two ? __dmul_rn(r, r) : pow(r, beta));
         }
     }
     __syncthreads();
     if (f >= frames) return;
-    // segment lengths in parallel (kept in place of my[] after use), then the ordered running sum
-    double seg[4];  // n <= 256
+    // segment lengths in parallel: lane l holds those of points l, l + 64, l + 128, l + 192 (n <= 256)
+    double seg[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int i = lane + 64 * c;
@@ -279,25 +318,26 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
             seg[c] = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    // The ordered running sum of the reference's loop (d_i = d_{i-1} + seg_i, same order: bit-identical).  Every lane runs
+    // the same chain on wave-uniform operands read out of the owners' registers (v_readlane: no LDS round trip per step,
+    // the only dependent operation per step is the add) and keeps the value that belongs to its own points; the row is
+    // then stored with all lanes (round 2: lane 0 walked LDS and issued 100 single-lane 8-byte stores per frame).
+    double d = 0.0, mine[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (64 * c >= n) break;
+        const int lim = min(64, n - 64 * c);
+        for (int l = 0; l < lim; ++l) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(seg[c]), l), hi = __builtin_amdgcn_readlane(__double2hiint(seg[c]), l);
+            d = __dadd_rn(__hiloint2double(hi, lo), d);     // seg of point 0 is 0.0: d_0 = 0
+            mine[c] = l == lane ? d : mine[c];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int i = lane + 64 * c;
-        if (i < n) mx[i] = seg[c];
+        if (i < n) dists[f * n + i] = mine[c];
     }
-    __builtin_amdgcn_wave_barrier();
-    // the ordered running sum (lane 0, through LDS: its only dependent chain is the add), then every lane stores its share
-    // of the row: 100 single-lane 8-byte stores per frame had made this the longest part of the kernel
-    if (lane == 0) {
-        double d = 0.0;
-        my[0] = 0.0;
-        for (int i = 1; i < n; ++i) {
-            d = __dadd_rn(mx[i], d);
-            my[i] = d;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < n; i += 64) dists[f * n + i] = my[i];
 }
 
 // ---------------------------------------------------------------- evenly spaced resampling of fx over x (fp64 in, fp32 out)
@@ -306,30 +346,37 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
 // binary search of the segment.
 __global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ x, const double* __restrict__ fx, long frames,
                                                        int n_pts, int n_samples, float* __restrict__ out) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= frames * n_samples) return;
-    const long f = idx / n_samples;
-    const int s = (int)(idx - f * n_samples);
-    const double* xf = x + f * n_pts;
-    const double* yf = fx + f * n_pts;
+    // one workgroup per frame: the frame's abscissae and values staged in LDS once (the binary search of every sample was a
+    // chain of dependent global loads), then one thread per sample
+    extern __shared__ __attribute__((aligned(16))) double rs[];   // [2][n_pts]
+    const long f = blockIdx.x;
+    double* xf = rs;
+    double* yf = rs + n_pts;
+    for (int i = threadIdx.x; i < n_pts; i += 256) {
+        xf[i] = x[f * n_pts + i];
+        yf[i] = fx[f * n_pts + i];
+    }
+    __syncthreads();
     const double x0 = xf[0], x1 = xf[n_pts - 1];
     const double step = n_samples > 1 ? __ddiv_rn(__dsub_rn(x1, x0), (double)(n_samples - 1)) : 0.0;
-    const double xq = s == n_samples - 1 && n_samples > 1 ? x1 : __dadd_rn(x0, __dmul_rn((double)s, step));
-    // largest i with xf[i] <= xq (clamped to the last segment)
-    int lo = 0, hi = n_pts - 1;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (xf[mid] <= xq) lo = mid; else hi = mid;
+    for (int s = threadIdx.x; s < n_samples; s += 256) {
+        const double xq = s == n_samples - 1 && n_samples > 1 ? x1 : __dadd_rn(x0, __dmul_rn((double)s, step));
+        // largest i with xf[i] <= xq (clamped to the last segment)
+        int lo = 0, hi = n_pts - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xf[mid] <= xq) lo = mid; else hi = mid;
+        }
+        double y;
+        if (n_pts == 1 || xf[hi] == xf[lo]) y = yf[lo];
+        else {
+            const double slope = __ddiv_rn(__dsub_rn(yf[hi], yf[lo]), __dsub_rn(xf[hi], xf[lo]));
+            y = __dadd_rn(__dmul_rn(slope, __dsub_rn(xq, xf[lo])), yf[lo]);
+            if (xq >= xf[hi]) y = yf[hi];
+        }
+        out[(f * 2) * n_samples + s] = (float)xq;
+        out[(f * 2 + 1) * n_samples + s] = (float)y;
     }
-    double y;
-    if (n_pts == 1 || xf[hi] == xf[lo]) y = yf[lo];
-    else {
-        const double slope = __ddiv_rn(__dsub_rn(yf[hi], yf[lo]), __dsub_rn(xf[hi], xf[lo]));
-        y = __dadd_rn(__dmul_rn(slope, __dsub_rn(xq, xf[lo])), yf[lo]);
-        if (xq >= xf[hi]) y = yf[hi];
-    }
-    out[(f * 2) * n_samples + s] = (float)xq;
-    out[(f * 2 + 1) * n_samples + s] = (float)y;
 }
 
 // ---------------------------------------------------------------- wall / semipolar-grid intersection (fp64)
@@ -573,8 +620,9 @@ extern "C" int as_tract_variables_fwd(const float* contours, int64_t frames, int
                                       int32_t n_tv, float* values, float* poc1, float* poc2, int32_t* idx, void* stream) {
     AS_REQUIRE(contours && spec && values && poc1 && poc2 && frames > 0 && A > 0 && N > 0 && n_tv > 0, AS_ERR_BAD_ARG,
                "as_tract_variables_fwd: bad argument");
-    const size_t shm = (size_t)A * 2 * N * sizeof(float);
+    const size_t shm = ((size_t)((A * 2 * N + 3) & ~3) + 4 * 2 * TV_MAXPTS) * sizeof(float);
     AS_REQUIRE(shm <= 64 * 1024 && frames < (1LL << 31), AS_ERR_UNSUPPORTED, "as_tract_variables_fwd: frame of %d x 2 x %d floats", A, N);
+    AS_REQUIRE(N <= TV_MAXPTS, AS_ERR_UNSUPPORTED, "as_tract_variables_fwd: %d points per contour > %d", N, TV_MAXPTS);
     hipLaunchKernelGGL(tv_kernel, dim3((unsigned)frames), dim3(256), shm, (hipStream_t)stream, contours,
                        (long)frames, A, N, spec, n_tv, values, poc1, poc2, idx);
     AS_LAUNCH_CHECK("as_tract_variables_fwd");
@@ -597,9 +645,9 @@ extern "C" int as_area_function_fwd(const double* internal_wall, const double* e
 extern "C" int as_evenly_spaced_fx(const double* x, const double* fx, int64_t frames, int32_t n_pts, int32_t n_samples, float* out,
                                    void* stream) {
     AS_REQUIRE(x && fx && out && frames > 0 && n_pts > 0 && n_samples > 0, AS_ERR_BAD_ARG, "as_evenly_spaced_fx: bad argument");
-    const long total = (long)frames * n_samples;
-    hipLaunchKernelGGL(resample_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fx, (long)frames, n_pts,
-                       n_samples, out);
+    AS_REQUIRE(n_pts <= 4096 && frames < (1LL << 31), AS_ERR_UNSUPPORTED, "as_evenly_spaced_fx: n_pts=%d must be <= 4096", n_pts);
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)frames), dim3(256), (size_t)2 * n_pts * sizeof(double), (hipStream_t)stream, x, fx,
+                       (long)frames, n_pts, n_samples, out);
     AS_LAUNCH_CHECK("as_evenly_spaced_fx");
     return 0;
 }
