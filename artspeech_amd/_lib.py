@@ -35,7 +35,9 @@ class Layout(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("gru_dropout", C.c_float), ("dropout_seed", C.c_uint64), ("dout_presigmoid", C.c_int32),
-                ("defer_dw2", C.c_int32), ("fold_wait_event", C.c_void_p)]
+                ("defer_dw2", C.c_int32), ("fold_wait_event", C.c_void_p),
+                ("loss_targets", C.c_void_p), ("loss_tgt_T", C.c_int64), ("loss_scale", C.c_float), ("loss_out", C.c_void_p),
+                ("loss_dout", C.c_void_p)]
 
 
 class Gemm(C.Structure):

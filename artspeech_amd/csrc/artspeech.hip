@@ -38,7 +38,7 @@ struct Carve {
 
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
-    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, slab3, bits1, bits2, total;
+    int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, slab3, bits1, bits2, lpart, lpart_n, total;
 };
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
@@ -73,6 +73,8 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.slab3 = c.take(SLAB_FLOATS);  // same, second side stream
     w.bits1 = c.take(rows * A * (D / 64) * 2);  // ReLU masks of r1 / r2: one bit per element (64-bit words, 16-byte aligned)
     w.bits2 = c.take(rows * A * (D / 64) * 2);
+    w.lpart_n = (rows / 32 + 2) * A;      // workgroup partial sums of the fused criterion (one per output-layer tile)
+    w.lpart = c.take(w.lpart_n);
     w.total = c.off;
     return w;
 }
@@ -167,8 +169,11 @@ int head_fold(const as_dims& d, const as_layout& L, const float* P, int64_t rows
     return 0;
 }
 
+// crit (optional): the training criterion fused into the output layer (as_opts.loss_*; lengths / T of the batch)
+struct Criterion { const float* tgt; long tgt_T; const int* lengths; int T; float scale; float* loss; float* dout; };
+
 int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const float* x, int64_t rows, float* out, float* ws,
-                  hipStream_t st) {
+                  hipStream_t st, const Criterion* crit = nullptr) {
     (void)P;
     const int A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
     const HeadWs w = head_ws(d, rows);
@@ -222,8 +227,27 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     l3.M = R; l3.N = O; l3.K = D; l3.batch = A; l3.act = 2; l3.epi = 0;
     {
         AS_PROF("head.gemm3", st);
-        took = as_lin_try(&l3, st);
+        // 64 x 128-column tiles of one head each, four workgroups per CU (lin_out_kernel); with `crit` the masked Euclidean
+        // criterion and its gradient ride in the epilogue
+        as_lin_out lo{};
+        lo.A = ws + w.r2hat; lo.lda = AD; lo.a_batch = D;
+        lo.B = ws + w.w3f; lo.ldb = D; lo.b_batch = (long)Opad * D; lo.b_rows = Opad;
+        lo.bias = ws + w.b3f; lo.bias_batch = O;
+        lo.out = out; lo.ldo = (long)A * O; lo.o_batch = O;
+        lo.M = R; lo.N = O; lo.K = D; lo.batch = A;
+        int n_part = 0;
+        if (crit) {
+            lo.tgt = crit->tgt; lo.tgt_T = crit->tgt_T; lo.lengths = crit->lengths; lo.T = crit->T; lo.scale = crit->scale;
+            lo.dout = crit->dout; lo.partial = ws + w.lpart; lo.partial_capacity = w.lpart_n;
+        }
+        took = as_lin_out_try(&lo, &n_part, st);
         AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
+        AS_REQUIRE(took || !crit, AS_ERR_UNSUPPORTED, "as_artspeech_fwd: the fused criterion needs 2 N <= 128 outputs per head (N = %d)", d.n_samp);
+        if (took && crit) AS_TRY(as_loss_final(ws + w.lpart, n_part, crit->scale, crit->loss, st));
+        if (!took) {
+            took = as_lin_try(&l3, st);
+            AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
+        }
     }
     if (!took)
         AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, AD, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D,
@@ -604,6 +628,12 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     if (sd && hipStreamWaitEvent(st, sd->join, 0) != hipSuccess) {  // folded weights ready before head GEMM 1
         as_set_error("as_artspeech_fwd: stream wait failed");
         return AS_ERR_BAD_ARG;
+    }
+    if (opts && opts->loss_targets) {
+        AS_REQUIRE(train && lengths && opts->loss_out && opts->loss_dout && opts->loss_tgt_T >= T, AS_ERR_BAD_ARG,
+                   "as_artspeech_fwd: fused criterion needs train, lengths, loss_out, loss_dout and loss_tgt_T >= T");
+        const Criterion crit{opts->loss_targets, (long)opts->loss_tgt_T, lengths, T, opts->loss_scale, opts->loss_out, opts->loss_dout};
+        return head_fwd_impl(*d, L, P, ws + w.lin, R, out, ws + w.head, st, &crit);
     }
     return head_fwd_impl(*d, L, P, ws + w.lin, R, out, ws + w.head, st);
 }

@@ -34,6 +34,22 @@ struct as_lin {
 };
 int as_lin_try(const as_lin* a, hipStream_t st);
 
+// lin_f32.hip: the heads' output layer out[M][batch][N] = sigmoid(A[M][batch][K] . B[batch][>= 128 rows][K]^T + bias), N <= 128,
+// optionally with the masked Euclidean criterion fused (tgt != NULL): loss partials (one per workgroup, `partial`, at most
+// partial_capacity) and d loss / d(pre-sigmoid) in `dout` (layout of out).  1 = launched, 0 = not a case, < 0 = error.
+struct as_lin_out {
+    const float* A; long lda, a_batch;
+    const float* B; long ldb, b_batch; int b_rows;
+    const float* bias; long bias_batch;
+    float* out; long ldo, o_batch;
+    int M, N, K, batch;
+    const float* tgt; long tgt_T; const int* lengths; int T; float scale;
+    float* dout; float* partial; long partial_capacity;
+};
+int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st);
+// metrics.hip: *loss = scale * sum of the first n partials (fixed order)
+int as_loss_final(const float* partial, int n, float scale, float* loss, hipStream_t st);
+
 // gru.hip: backward recurrence of layer 0 under a token table; see the kernel.  1 = launched, 0 = not a case, < 0 = error.
 bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T);   // the [V][3H] table + T offsets fit the kernel's LDS budget
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,

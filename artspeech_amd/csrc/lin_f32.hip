@@ -338,6 +338,153 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Output layer of the heads: out = sigmoid(x_hat . W3'^T + b3') (models.py:28-31, 145), N = 2 x n_samples <= 128 columns per
+// head, optionally with the training criterion fused into the epilogue (EuclideanDistance + padding mask + mean,
+// phoneme_to_articulation/metrics.py:17-24, train_phoneme_to_articulation.py:86-90, and its gradient through the sigmoid).
+// One workgroup = 64 frames x the (<= 128) outputs of ONE head: 2 x 4 waves, a wave owns 32 rows x 32 columns (one
+// accumulator), so none of the eight waves multiplies padding beyond the N -> 128 round-up (the 256-column kernel above would
+// leave four of its eight waves on zeros).  36 KB of LDS, < 64 VGPRs: four workgroups per CU.  Same LDS-DMA ring as above
+// (16-deep k-tiles, XOR-swizzled 16-byte chunks, counted vmcnt, raw barriers); every wave issues one A piece (waves 4-7
+// repeat pieces 0-3) and one B piece per k-tile.
+// Fused criterion: the x coordinates (columns [0, N/2)) and y coordinates ([N/2, N)) of a point lie in different waves, so
+// the sigmoid outputs of the tile meet in LDS (the ring's memory); a thread then owns (frame, point) pairs: distance to the
+// target, its share of the masked sum, and d loss / d(pre-sigmoid) written where the backward expects d(out).  Partial sums
+// leave per workgroup and are added in a fixed order by loss_final (deterministic).
+constexpr int ON = 128;
+
+struct LinOutK {
+    const float* A; long lda, a_batch;       // x_hat [M][batch][K]
+    const float* B; long ldb, b_batch; int b_rows;   // W3' [batch][b_rows >= N][K] (rows N .. b_rows-1 zero)
+    const float* bias; long bias_batch;
+    float* out; long ldo, o_batch;           // [M][batch][N]
+    int M, N, K, batch;
+    int n_big, big_per_batch, big_per_batch_rows, small_per_batch;
+    // fused criterion (tgt == nullptr: plain output layer)
+    const float* tgt; long tgt_T; const int* lengths; int T; float scale;
+    float* dout; float* partial;
+};
+
+__global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
+    constexpr int TILE = BK * (64 + ON);
+    constexpr int RING = NBUF * TILE;            // 9216 floats = 36 KB; the epilogue's [64][ON] tile (32 KB) reuses it
+    __shared__ __attribute__((aligned(16))) float smem[RING];
+    int bz, m0, rows;
+    if ((int)blockIdx.x < g.n_big) {
+        bz = blockIdx.x / g.big_per_batch;
+        m0 = (blockIdx.x - bz * g.big_per_batch) * 64;
+        rows = 64;
+    } else {
+        const int j = blockIdx.x - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        rows = 32;
+    }
+    const float* __restrict__ A = g.A + (long)bz * g.a_batch;
+    const float* __restrict__ B = g.B + (long)bz * g.b_batch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    // DMA sources: A piece = wave & 3 (16 rows x 16 k), B piece = wave (16 output rows x 16 k); chunk swizzle as above
+    const int pa = wave & 3;
+    const int ra = pa * 16 + (lane >> 2);
+    const int a_gc = ((lane & 3) ^ ((ra >> 2) & 3)) * 4;
+    const float* a_src = A + (long)min(m0 + ra, g.M - 1) * g.lda + a_gc;
+    const int rb = wave * 16 + (lane >> 2);
+    const int b_gc = ((lane & 3) ^ ((rb >> 2) & 3)) * 4;
+    const float* b_src = B + (long)min(rb, g.b_rows - 1) * g.ldb + b_gc;   // rows beyond the head's own only feed columns >= N
+    const unsigned smem_base = lds_addr(smem);
+    auto issue = [&](int kt) {
+        const unsigned base = smem_base + (unsigned)((kt % NBUF) * TILE) * 4u;
+        glds16(a_src + kt * BK, base + (unsigned)(pa * 1024));
+        glds16(b_src + kt * BK, base + (unsigned)((BK * 64 + wave * 256) * 4));
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = g.K / BK;
+    const int swz = (l31 >> 2) & 3;
+    const bool active = wm == 0 || rows == 64;      // a 32-row tile has one row block: waves 4-7 only help with the DMAs
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) issue(kt + 2);
+        const float* tile = smem + (kt % NBUF) * TILE;
+        const float* a_s = tile + (wm * 32 + l31) * BK;
+        const float* b_s = tile + BK * 64 + (wn * 32 + l31) * BK;
+        if (active) {
+#pragma unroll
+            for (int cc = 0; cc < BK / 8; ++cc) {
+                const int slot = ((2 * cc + lh) ^ swz) * 4;
+                const float4 av = *reinterpret_cast<const float4*>(a_s + slot);
+                const float4 bv = *reinterpret_cast<const float4*>(b_s + slot);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+        }
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // ---- epilogue.  D[row][col]: col = wn * 32 + l31, row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh
+    const int col = wn * 32 + l31;
+    const float bj = (g.bias && col < g.N) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    if (g.tgt == nullptr) {
+        if (active && col < g.N) {
+            float* o0 = g.out + (long)bz * g.o_batch + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M) o0[(long)row * g.ldo] = as_sigmoid(acc[r] + bj);
+            }
+        }
+        return;
+    }
+    // fused criterion: sigmoid outputs through LDS ([64][ON]; every ring read is behind the loop's last barrier)
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ON + col] = as_sigmoid(acc[r] + bj);
+    }
+    lds_barrier();
+    const int Np = g.N >> 1;                                    // points per contour
+    float part = 0.f;
+    for (int p = tid; p < rows * Np; p += NT) {
+        const int r = p / Np, n = p - r * Np;
+        const long frame = (long)m0 + r;
+        if (frame >= g.M) continue;
+        const float ox = smem[r * ON + n], oy = smem[r * ON + Np + n];
+        float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
+        o[n] = ox;
+        o[Np + n] = oy;
+        const long b = frame / g.T;
+        const int t = (int)(frame - b * g.T);
+        float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
+        if (t < g.lengths[b]) {
+            const float* tg = g.tgt + ((b * g.tgt_T + t) * g.batch + bz) * g.N;
+            const float dx = ox - tg[n], dy = oy - tg[Np + n];
+            const float d = sqrtf(dx * dx + dy * dy);
+            part += d;
+            const float gg = g.scale / d;                       // NaN at zero distance, as torch autograd
+            dz[n] = dx * gg * ox * (1.f - ox);                   // through the sigmoid (same product order as the unfused kernels)
+            dz[Np + n] = dy * gg * oy * (1.f - oy);
+        } else {
+            dz[n] = 0.f;
+            dz[Np + n] = 0.f;
+        }
+    }
+    part = wave_sum(part);
+    __shared__ float red[8];
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    if (tid == 0) g.partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Tile list.  Two workgroups per CU = 512 slots; a launch of T equal tiles takes ceil(T / 512) rounds, and the head
@@ -413,4 +560,42 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     }
     if (a->b_kc) return launch<true, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
     return launch<false, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
+}
+
+// Output layer of the heads, optionally with the masked Euclidean criterion and its gradient fused in (see lin_out_kernel).
+// 1 = launched (fused: *n_partials workgroup sums were written to `partial`), 0 = not a case, < 0 = error.
+int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st) {
+    static const bool off = AS_DIAG_SET("AS_NO_LIN_OUT");  // ablation: the general GEMM (+ the separate criterion kernel)
+    if (off) return 0;
+    if (a->K % BK || a->K < BK || a->N > ON || a->N < 4 || a->N % 2 || a->M < 1 || a->batch < 1) return 0;
+    if (!aligned16(a->A) || !aligned16(a->B) || a->lda % 4 || a->ldb % 4 || a->a_batch % 4 || a->b_batch % 4) return 0;
+    if (a->b_rows < a->N) return 0;
+    LinOutK k{};
+    k.A = a->A; k.lda = a->lda; k.a_batch = a->a_batch;
+    k.B = a->B; k.ldb = a->ldb; k.b_batch = a->b_batch; k.b_rows = a->b_rows;
+    k.bias = a->bias; k.bias_batch = a->bias_batch;
+    k.out = a->out; k.ldo = a->ldo; k.o_batch = a->o_batch;
+    k.M = a->M; k.N = a->N; k.K = a->K; k.batch = a->batch;
+    k.tgt = a->tgt; k.tgt_T = a->tgt_T; k.lengths = a->lengths; k.T = a->T; k.scale = a->scale; k.dout = a->dout; k.partial = a->partial;
+    if (k.tgt && (!k.lengths || !k.dout || !k.partial || k.T < 1 || k.ldo != (long)k.batch * k.N || k.o_batch != k.N)) return 0;
+    // tile list as for the 256-column kernel: 64-row tiles that fill whole rounds of the 4 x 256 resident slots, 32-row tiles
+    // over the rest
+    constexpr int slots = 1024;
+    const long units = (long)as_cdiv(k.M, 64) * k.batch;
+    const long rounds = units / slots;
+    int x = (int)(rounds * slots / k.batch);
+    if (x > k.M / 64) x = k.M / 64;
+    if (rounds == 0) x = k.M / 64;                       // less than one round: plain 64-row tiles (+ a ragged end)
+    const int rest = k.M - x * 64;
+    k.big_per_batch = x > 0 ? x : 1;
+    k.big_per_batch_rows = x * 64;
+    k.n_big = x * k.batch;
+    k.small_per_batch = as_cdiv(rest, 32);
+    const long total = (long)k.n_big + (long)k.small_per_batch * k.batch;
+    if (k.small_per_batch == 0) k.small_per_batch = 1;
+    if (k.tgt && total > a->partial_capacity) return 0;
+    hipLaunchKernelGGL(lin_out_kernel, dim3((unsigned)total), dim3(NT), 0, st, k);
+    AS_LAUNCH_CHECK("as_lin_out");
+    if (n_partials) *n_partials = (int)total;
+    return 1;
 }

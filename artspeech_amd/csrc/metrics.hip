@@ -3,7 +3,7 @@
 //   P2CPDistance utterance means, tract variables (min pairwise distance + closest pair) and the
 //   vocal-tract area function (fp64).  One wave per tile/frame where a tile is small; coalesced
 //   4-byte lanes over the (.., 2, N) contour rows (N = 50 floats = 200 B rows are only 8-byte aligned).
-#include "as_common.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -549,6 +549,13 @@ extern "C" int as_euclid_bwd(const float* out, const float* tgt, const float* dd
 }
 
 extern "C" int32_t as_euclid_masked_partials(void) { return LOSS_BLOCKS; }
+
+// internal (gemm_internal.h): the final, fixed-order sum of workgroup partials written by another kernel
+int as_loss_final(const float* partial, int n, float scale, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, n, scale, loss);
+    AS_LAUNCH_CHECK("as_loss_final");
+    return 0;
+}
 
 namespace {
 template <bool PRESIG>

@@ -62,10 +62,12 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(self.grads)
         self.steps = 0
         self.bwd_opts = _lib.Opts(0.0, 0, 1, 1 if self.pipeline else 0, None)
+        self.fwd_opts = _lib.Opts(0.0, 0, 0, 0, None)
+        # criterion fused into the output layer of the heads (as_opts.loss_*): needs 2 N <= 128 outputs per head
+        self.fuse_loss = 2 * d.n_samp <= 128
         if self.pipeline:
             self.late_stream = torch.cuda.Stream(device=dev)
             self.late_event = torch.cuda.Event()
-            self.fwd_opts = _lib.Opts(0.0, 0, 0, 0, None)
 
     def forward_backward(self, tokens, lengths_dev, targets, loss_scale):
         """tokens (B, >=T) int64, lengths_dev (B,) int32 on device, targets (B, >=T, A, 2, N).
@@ -73,18 +75,25 @@ class TrainStep:
         L, d, st = _lib.lib(), self.dims, _lib.stream_ptr()
         P = self.model.flat.data
         B, T = self.B, self.T
-        fwd_opts = None
+        fo = self.fwd_opts
+        fo.fold_wait_event = None
+        if self.fuse_loss:
+            fo.loss_targets, fo.loss_tgt_T, fo.loss_scale = targets.data_ptr(), targets.shape[1], float(loss_scale)
+            fo.loss_out, fo.loss_dout = self.loss.data_ptr(), self.dout.data_ptr()
+        fwd_opts = C.byref(fo) if self.fuse_loss else None
         if self.pipeline and self.pending is not None:
             # the previous step's late slice: weight gradient -> all-reduce -> Adam on the side stream, beside this step's
             # forward recurrences; the forward's fold of the head weights waits for late_event, the recurrences do not
             self._late_update(self.late_stream)
             self.late_event.record(self.late_stream)
-            self.fwd_opts.fold_wait_event = self.late_event.cuda_event
-            fwd_opts = C.byref(self.fwd_opts)
+            fo.fold_wait_event = self.late_event.cuda_event
+            fwd_opts = C.byref(fo)
         _lib.check(L.as_artspeech_fwd(C.byref(d), _lib.ptr(P), _lib.ptr(tokens), tokens.stride(0), _lib.ptr(lengths_dev),
                                       B, T, _lib.ptr(self.out), _lib.ptr(self.ws), 1, fwd_opts, st), "as_artspeech_fwd")
         # criterion backward and the model's final sigmoid backward in one pass: dout holds d(loss)/d(pre-sigmoid)
-        _lib.check(L.as_euclid_masked_fwd_bwd_presigmoid(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1],
+        # (fused into the forward's output layer when the head is narrow enough: nothing to do here then)
+        if not self.fuse_loss:
+            _lib.check(L.as_euclid_masked_fwd_bwd_presigmoid(_lib.ptr(self.out), _lib.ptr(targets), targets.shape[1],
                                                          _lib.ptr(lengths_dev), B, T, d.n_art, d.n_samp, float(loss_scale),
                                                          _lib.ptr(self.loss), _lib.ptr(self.dout), _lib.ptr(self.partial), st),
                    "as_euclid_masked_fwd_bwd_presigmoid")

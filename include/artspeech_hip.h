@@ -101,6 +101,13 @@ typedef struct as_opts {
        not wait.  Same arithmetic on the same operands as the unpipelined step: bit-identical parameters. */
     int32_t defer_dw2;
     void* fold_wait_event;
+    /* as_artspeech_fwd (training engine): the criterion of train_phoneme_to_articulation.py:86-90 fused into the epilogue of
+       the heads' output layer.  loss_targets != NULL (float [B][loss_tgt_T][A][2][N] on the device, loss_tgt_T >= T): the
+       forward also writes *loss_out = loss_scale * sum over valid frames of the point distances (loss_scale = 1 / (valid
+       frames * A * N); a device scalar) and loss_dout [B][T][A][2][N] = d loss / d(pre-sigmoid activations), which
+       as_artspeech_bwd takes as `dout` with dout_presigmoid set -- the separate pass of as_euclid_masked_fwd_bwd_presigmoid
+       over the 28 MB of contours and targets disappears.  `out` is written as usual.  Needs 2 N <= 128. */
+    const float* loss_targets; int64_t loss_tgt_T; float loss_scale; float* loss_out; float* loss_dout;
 } as_opts;
 
 /* ArtSpeech.forward / SimpleArtSpeech.forward (encoder_decoder/models.py:126-145, 75-96).

@@ -507,3 +507,34 @@ def test_hbm_resident_dataset_collates_like_the_host_collate(dev):
     a = tr.run_epoch(VALID, 1, model, DataLoader(ds, batch_size=8, shuffle=False, collate_fn=pad_sequence_collate_fn), opt, crit, device=dev)
     b = tr.run_epoch(VALID, 1, model, DataLoader(rds, batch_size=8, shuffle=False, collate_fn=rds.collate), opt, crit, device=dev)
     assert a["loss"] == b["loss"]
+
+
+def test_criterion_fused_into_the_output_layer_equals_the_separate_kernel(dev):
+    """TrainStep asks as_artspeech_fwd to fuse the masked Euclidean criterion (and its gradient through the sigmoid) into the
+    epilogue of the heads' output layer (as_opts.loss_*).  Against the same engine with the separate criterion kernel:
+    contours and every gradient bit for bit (same arithmetic per element), the loss to summation order (1e-7)."""
+    from artspeech_amd.engine import TrainStep
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    V, A, B, T = 45, 4, 8, 100                      # 800 frames: 64-row tiles + a ragged 32-row tail per head
+    lengths = torch.tensor([100, 97, 64, 63, 40, 33, 8, 1], dtype=torch.int32)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(1, V, (B, T), generator=g)
+    tgt = torch.rand(B, T + 3, A, 2, 50, generator=g)       # targets padded beyond T: tgt_T > T
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+    x, tgt, ld = x.to(dev), tgt.to(dev), lengths.to(dev)
+    scale = 1.0 / (float(lengths.sum()) * A * 50)
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(2)
+        model = ArtSpeech(V, A).to(dev)
+        step = TrainStep(model, B, T, optimizer=False)
+        assert step.fuse_loss
+        step.fuse_loss = fused
+        step.forward_backward(x, ld, tgt, scale)
+        torch.cuda.synchronize()
+        res.append((step.out.clone(), step.dout.clone(), step.grads.clone(), float(step.loss)))
+    assert torch.equal(res[0][0], res[1][0]), "contours differ"
+    assert torch.equal(res[0][1], res[1][1]), "d loss / d(pre-sigmoid) differs"
+    assert torch.equal(res[0][2], res[1][2]), "gradients differ"
+    assert abs(res[0][3] - res[1][3]) < 1e-7 and np.isfinite(res[0][3])
