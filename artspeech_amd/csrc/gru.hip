@@ -589,8 +589,9 @@ constexpr int lpu_of(int) { return 4; }
 }  // namespace
 
 static unsigned long long* g_gru_dbg = nullptr;
+static unsigned g_gru_dbg_launch = 0;   // stamps of consecutive backward launches alternate between two halves of the buffer
 constexpr int AS_GRU_TOK_LDS_MAX = 128 * 1024;   // token-sum table of the layer-0 backward recurrence (one workgroup per CU)
-extern "C" void as_gru_debug_stamps(uint64_t* buf) { g_gru_dbg = (unsigned long long*)buf; }
+extern "C" void as_gru_debug_stamps(uint64_t* buf) { g_gru_dbg = (unsigned long long*)buf; g_gru_dbg_launch = 0; }
 
 static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
                           const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y, float* gates, int nd, void* stream,
@@ -666,6 +667,9 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
     AS_REQUIRE((long)B * T * 8 * H * 4 < (1L << 32), AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: B*T=%ld frames exceed the 32-bit offsets", (long)B * T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, 2);
+    // diagnostic stamps (as_gru_debug_stamps): 2 x (2 B workgroups x 4 words); launch k writes half k % 2, so that the two
+    // backward recurrences of one training step (layer 1, then layer 0) can both be read afterwards
+    unsigned long long* dbg_now = g_gru_dbg ? g_gru_dbg + (size_t)(g_gru_dbg_launch++ & 1u) * 8u * (size_t)B : nullptr;
 #ifdef AS_DIAG
     static const bool unit_layout = AS_DIAG_SET("AS_GRU_BWD_UNIT");  // ablation: the 4-lanes-per-unit layout
 #endif
@@ -681,7 +685,7 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
             AS_REQUIRE(attr == hipSuccess, (int)attr, "as_gru_bidir_bwd: cannot reserve LDS: %s", hipGetErrorString(attr));   \
         }                                                                                                                     \
         hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), TK ? shm : 0, st, dy, y, gates, w_hh,        \
-                           lengths, T, dgi, dgh, g_gru_dbg, tokens, (long)tok_stride, V, part);                               \
+                           lengths, T, dgi, dgh, dbg_now, tokens, (long)tok_stride, V, part);                                 \
     } while (0)
 #ifdef AS_DIAG   // other look-aheads and the 4-lanes-per-unit layout exist in the diagnostic build only
 #define AS_GRU_BWD(HH)                                                                                                        \

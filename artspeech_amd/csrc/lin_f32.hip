@@ -453,29 +453,34 @@ __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
     }
     lds_barrier();
     const int Np = g.N >> 1;                                    // points per contour
+    // one wave per frame (row) at a time, lanes over the points: frame index, utterance, validity and the target row are
+    // wave-uniform (computed once per row on the scalar unit, no per-pair divisions); rows of a wave are independent, so
+    // the next row's target loads are in flight while this row's stores go out
     float part = 0.f;
-    for (int p = tid; p < rows * Np; p += NT) {
-        const int r = p / Np, n = p - r * Np;
-        const long frame = (long)m0 + r;
-        if (frame >= g.M) continue;
-        const float ox = smem[r * ON + n], oy = smem[r * ON + Np + n];
-        float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
-        o[n] = ox;
-        o[Np + n] = oy;
-        const long b = frame / g.T;
-        const int t = (int)(frame - b * g.T);
-        float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
-        if (t < g.lengths[b]) {
-            const float* tg = g.tgt + ((b * g.tgt_T + t) * g.batch + bz) * g.N;
-            const float dx = ox - tg[n], dy = oy - tg[Np + n];
-            const float d = sqrtf(dx * dx + dy * dy);
-            part += d;
-            const float gg = g.scale / d;                       // NaN at zero distance, as torch autograd
-            dz[n] = dx * gg * ox * (1.f - ox);                   // through the sigmoid (same product order as the unfused kernels)
-            dz[Np + n] = dy * gg * oy * (1.f - oy);
-        } else {
-            dz[n] = 0.f;
-            dz[Np + n] = 0.f;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int r = wave_u; r < rows; r += 8) {
+        const int frame = m0 + r;
+        if (frame >= g.M) break;
+        const int b = frame / g.T, t = frame - b * g.T;
+        const bool valid = t < g.lengths[b];
+        float* o = g.out + (long)frame * g.ldo + (long)bz * g.o_batch;
+        float* dz = g.dout + (long)frame * g.ldo + (long)bz * g.o_batch;
+        const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
+        for (int n = lane; n < Np; n += 64) {
+            const float ox = smem[r * ON + n], oy = smem[r * ON + Np + n];
+            o[n] = ox;
+            o[Np + n] = oy;
+            float gx = 0.f, gy = 0.f;
+            if (valid) {
+                const float dx = ox - tg[n], dy = oy - tg[Np + n];
+                const float d = sqrtf(dx * dx + dy * dy);
+                part += d;
+                const float gg = g.scale / d;                   // NaN at zero distance, as torch autograd
+                gx = dx * gg * ox * (1.f - ox);                  // through the sigmoid (same product order as the unfused kernels)
+                gy = dy * gg * oy * (1.f - oy);
+            }
+            dz[n] = gx;
+            dz[Np + n] = gy;
         }
     }
     part = wave_sum(part);

@@ -430,8 +430,10 @@ void as_profile_reset(void);
  * launched without a buffer executes no stamp).  Per workgroup: s_memtime at start, after the prologue's first wait,
  * after the main loop, at the end; s_memrealtime at start; HW_ID and XCC_ID registers.  Never used by the product path. */
 void as_lin_debug_stamps(uint64_t* buf, int64_t max_workgroups);
-/* Diagnostic: per-workgroup stamps of the GRU backward recurrence (as_gru_bidir_bwd): buf = device array of 4 x 2 x B uint64
- * {shader cycles, 100 MHz wall ticks, sequence length, wall start} per (direction, utterance), or NULL (default: no stamps). */
+/* Diagnostic: per-workgroup stamps of the GRU backward recurrences: buf = device array of 2 x (4 x 2 x B) uint64, or NULL
+ * (default: no stamps).  Consecutive backward launches alternate between the two halves (a training step launches layer 1,
+ * then layer 0: half 0 and half 1 after a call that reset the counter); per (direction, utterance):
+ * {shader cycles, 100 MHz wall ticks, sequence length, wall start}. */
 void as_gru_debug_stamps(uint64_t* buf);
 int32_t as_profile_report(char* buf, int32_t buflen);
 

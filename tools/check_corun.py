@@ -52,7 +52,7 @@ def background(kind, n):
             _lib.check(L.as_layernorm_fwd(_lib.ptr(x), None, None, None, _lib.ptr(xh), None, _lib.ptr(rstd), 70400, 256, 0, side.cuda_stream))
 
 
-stamps = torch.zeros(2 * B * 4, dtype=torch.int64, device=dev)   # in-kernel stamps: cycles and wall ticks per workgroup
+stamps = torch.zeros(2 * 2 * B * 4, dtype=torch.int64, device=dev)   # in-kernel stamps: cycles and wall ticks per workgroup (two halves)
 L.as_gru_debug_stamps(_lib.ptr(stamps))
 main = torch.cuda.current_stream().cuda_stream
 for kind in ("alone", "gemm", "rows"):
@@ -68,7 +68,8 @@ for kind in ("alone", "gemm", "rows"):
         e1.record()
         torch.cuda.synchronize()
         times.append(1e3 * e0.elapsed_time(e1))
-    st = stamps.cpu().numpy().reshape(-1, 4)
+    st = stamps.cpu().numpy().reshape(2, -1, 4)
+    st = st[0] if st[0][:, 3].max() >= st[1][:, 3].max() else st[1]   # the half the LAST launch wrote (latest wall start)
     cyc, ticks = st[:, 0].astype(float), st[:, 1].astype(float)
     clock = float((cyc / ticks * 100).mean())   # MHz: shader cycles per 100 MHz wall tick, averaged over the 64 workgroups
     print(f"gru backward {kind:6s}: {min(times):7.1f} us/launch (min of 5), {sorted(times)[2]:7.1f} median | last launch, per workgroup: "

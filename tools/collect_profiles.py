@@ -2,7 +2,8 @@
   profiles/<tag>_kernel_stats.csv   -- `rocprofv3 --kernel-trace --stats` per-kernel summary (as emitted)
   profiles/<tag>_pmc_traffic.json   -- HBM bytes per launch per kernel from two separate --pmc passes
                                        (FETCH_SIZE, WRITE_SIZE), corrected as MI355X_MICROARCH.md prescribes
-usage: python tools/collect_profiles.py <tag> <stats_dir> <fetch_dir> <write_dir>"""
+usage: python tools/collect_profiles.py <tag> <stats_dir> <fetch_dir> <write_dir> [what]
+`what` (optional): a suffix for the two files, e.g. "metrics_kernels" -> profiles/<tag>_metrics_kernels_{kernel_stats.csv,pmc_traffic.json}"""
 import collections
 import csv
 import glob
@@ -12,6 +13,8 @@ import shutil
 import sys
 
 tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+if len(sys.argv) > 5:
+    tag = f"{tag}_{sys.argv[5]}"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)

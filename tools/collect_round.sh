@@ -1,24 +1,31 @@
 #!/bin/bash
 # Collect the round's measurement evidence on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards by
-# tools/collect_profiles.py and by hand).  usage (inside gpurun): bash tools/collect_round.sh r02
-set -e
-tag=${1:-r02}
-out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+# tools/collect_profiles.py and by hand).  usage (inside gpurun): bash tools/collect_round.sh r03
+source tools/gpu_steps.sh
+tag=${1:-r03}
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/bench.py > $out/bench_final.json 2> $out/bench_final.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/stats.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile > $out/fetch.json 2> $out/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile > $out/write.json 2> $out/write.log
-rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > $out/kt.log 2>&1
-python3 $GRAFT_REPO_ROOT/tools/step_timeline.py $out/kt/*/*_kernel_trace.csv > $out/step_timeline.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/tstep -- python3 $GRAFT_REPO_ROOT/tools/profile_transformer_step.py 32 200 2 > $out/tstep.log 2>&1
-cd $GRAFT_REPO_ROOT
-python3 tools/bench_wgrad.py 20 > $out/wgrad_microbench.log 2>&1
-ARTSPEECH_DIAG_LIB=1 AS_NO_WGRAD=1 python3 tools/bench_wgrad.py 20 >> $out/wgrad_microbench.log 2>&1
-python3 tools/bench_heads.py 20 > $out/heads_microbench.log 2>&1
-ARTSPEECH_DIAG_LIB=1 AS_NO_LIN=1 python3 tools/bench_heads.py 20 >> $out/heads_microbench.log 2>&1
-python3 tools/lin_stamps.py > $out/lin_stamps.log 2>&1
-hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $out/mfma_peak.log 2>&1
-python3 tools/bench_gru.py 20 > $out/recurrence_microbench.log 2>&1
+step 500 $out/bench_final.json python3 $R/bench.py
+step 300 $out/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras
+step 300 $out/fetch.json rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
+step 300 $out/write.json rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
+step 300 $out/kt.log rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras
+python3 $R/tools/step_timeline.py $(ls -t $out/kt/*/*_kernel_trace.csv | head -1) > $out/step_timeline.txt
+step 300 $out/mfma.json rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
+# the three small kernels north_star names: per-kernel time + HBM bytes of a driver-style loop
+step 200 $out/mk_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $out/mk_stats -- python3 $R/tools/bench_metrics_kernels.py 50
+step 200 $out/mk_fetch.log rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/mk_fetch -- python3 $R/tools/bench_metrics_kernels.py 10
+step 200 $out/mk_write.log rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/mk_write -- python3 $R/tools/bench_metrics_kernels.py 10
+step 400 $out/tstep.log rocprofv3 --kernel-trace --stats --output-format csv -d $out/tstep -- python3 $R/tools/profile_transformer_step.py 32 200 2
+cd $R
+step 120 $out/metrics_kernels.log python3 tools/bench_metrics_kernels.py 50 --json $out/metrics_kernels.json
+step 120 $out/recurrence_in_step.log python3 tools/recurrence_stamps.py 50
+step 120 $out/recurrence_microbench.log python3 tools/bench_gru.py 20
+step 120 $out/heads_microbench.log python3 tools/bench_heads.py 20
+step 120 $out/wgrad_microbench.log python3 tools/bench_wgrad.py 20
+step 300 $out/epoch.log python3 tools/bench_epoch.py 4
+step 120 $out/corun.log python3 tools/check_corun.py
+step 300 $out/bench_gpus2_rehearsal.json python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline
 echo done
