@@ -186,43 +186,56 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (stamp) g.dbg[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) issue(kt + 2);
-        const float* tile = smem + (kt % NBUF) * TILE;
+    // Main loop, software-pipelined across the k-tile boundary.  A k-tile is two 8-deep fragment groups; the barrier that
+    // ends a tile sits BETWEEN the two groups' MFMAs: when a wave reaches it, all its LDS reads of the tile are in registers
+    // and eight MFMAs are still to be issued, and right behind it the first fragments of the NEXT tile are requested, so
+    // the barrier's skew and the LDS round trip run under matrix work instead of in front of it (before: every tile began
+    // with all eight waves waiting for their first fragments, ~10 % of a 2048-cycle tile with the pipe idle).
+    struct Frag { float4 av[TM]; float bv[4]; };
+    auto load = [&](Frag& f, int kt_, int cc) {
+        const float* tile = smem + (kt_ % NBUF) * TILE;
         const float* a_s = tile + l31 * BK;
         const float* b_s = tile + BK * BM;
-        auto body = [&](auto tmc) {
-            constexpr int TMC = decltype(tmc)::value;
+        const int slot = ((2 * cc + lh) ^ swz) * 4;
 #pragma unroll
-            for (int cc = 0; cc < BK / 8; ++cc) {
-                const int slot = ((2 * cc + lh) ^ swz) * 4;
-                float4 av[TMC];
+        for (int i = 0; i < TM; ++i) f.av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + slot);
+        if (B_KC) {
+            const float4 t = *reinterpret_cast<const float4*>(b_s + (wave * 32 + l31) * BK + slot);
+            f.bv[0] = t.x; f.bv[1] = t.y; f.bv[2] = t.z; f.bv[3] = t.w;
+        } else {
 #pragma unroll
-                for (int i = 0; i < TMC; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + slot);
-                float bv[4];
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(b_s + (wave * 32 + l31) * BK + slot);
-                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-                } else {
+            for (int j = 0; j < 4; ++j) f.bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
+        }
+    };
+    auto mma = [&](const Frag& f) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
-                }
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int i = 0; i < TMC; ++i) {
-                        const float a = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[i], 0, 0, 0);
-                    }
+            for (int i = 0; i < TM; ++i) {
+                if (i < tm_eff) {   // (a 32-row tile owns only its first row block)
+                    const float a = j == 0 ? f.av[i].x : j == 1 ? f.av[i].y : j == 2 ? f.av[i].z : f.av[i].w;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.bv[j], acc[i], 0, 0, 0);
                 }
             }
-        };
-        if (tm_eff == TM) body(std::integral_constant<int, TM>{});
-        else body(std::integral_constant<int, 1>{});
+        }
+    };
+    static_assert(BK == 16, "two fragment groups per k-tile");
+    Frag f0, f1;
+    load(f0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) issue(kt + 2);
+        load(f1, kt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot kt % 3 are in registers
         __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) load(f0, kt + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (stamp) g.dbg[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     if (g.abl == 1) {
