@@ -451,12 +451,16 @@ StreamState* state_for(hipStream_t st) {
 }
 // the side stream of the caller's stream, or nullptr when overlap is off / unavailable
 StreamState* side_for(hipStream_t st) {
-    if (g_overlap < 0) g_overlap = getenv("ARTSPEECH_NO_OVERLAP") ? 0 : 1;
-    if (!g_overlap) return nullptr;
-    StreamState* p = state_for(st);
-    if (!p) return nullptr;
-    if (!p->side) {
+    {
         std::lock_guard<std::mutex> lock(g_state_mu);
+        if (g_overlap < 0) g_overlap = getenv("ARTSPEECH_NO_OVERLAP") ? 0 : 1;
+        if (!g_overlap) return nullptr;
+    }
+    StreamState* p = state_for(st);
+    if (!p) return nullptr;   // no state for this stream (table full, or first call inside a capture): in order on `st`
+    {
+        std::lock_guard<std::mutex> lock(g_state_mu);
+        if (p->side) return p;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
         if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
@@ -472,7 +476,10 @@ StreamState* side_for(hipStream_t st) {
 // them, so that a data-parallel host can start their all-reduce while the GRU backward is still running.
 int record_heads_done(hipStream_t owner, hipStream_t s) {
     StreamState* p = state_for(owner);
-    AS_REQUIRE(p, AS_ERR_UNSUPPORTED, "as_artspeech_bwd: no per-stream state (first call inside a stream capture?)");
+    // no per-stream state (more than 256 distinct caller streams, or the first call on a stream inside a capture): the
+    // backward itself does not need the event -- everything then runs in order on the caller's stream -- only
+    // as_artspeech_wait_head_grads() does, and it reports the missing state itself
+    if (!p) return 0;
     const hipError_t e = hipEventRecord(p->heads, s);
     AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_bwd: hipEventRecord failed: %s", hipGetErrorString(e));
     return 0;
@@ -490,7 +497,10 @@ int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
 
 }  // namespace
 
-extern "C" void as_set_overlap(int32_t on) { g_overlap = on ? 1 : 0; }
+extern "C" void as_set_overlap(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_state_mu);
+    g_overlap = on ? 1 : 0;
+}
 
 extern "C" int as_artspeech_wait_head_grads(void* compute_stream, void* waiting_stream) {
     StreamState* p = state_for((hipStream_t)compute_stream);

@@ -96,6 +96,9 @@ class _ArtSpeechFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flat, tokens, lengths_dev, dims, B, T, opts=None, defer=None):
         L = _lib.lib()
+        # `train` = keep what the backward needs.  Dropout (opts) is a property of the MODULE's mode, not of grad mode: the
+        # reference's nn.Dropout / nn.GRU(dropout=p) also drop under torch.no_grad() while model.training is set, so the C
+        # side is told to run in training mode whenever opts carry a dropout probability
         train = bool(ctx.needs_input_grad[0])  # (grad mode is always off inside Function.forward)
         out = torch.empty((B, T, dims.n_art, 2, dims.n_samp), dtype=torch.float32, device=flat.device)
         n_ws = L.as_artspeech_workspace_floats(C.byref(dims), B, T)
@@ -103,7 +106,7 @@ class _ArtSpeechFn(torch.autograd.Function):
             _lib.check(int(n_ws) or -1, "as_artspeech_workspace_floats")
         ws = torch.empty(n_ws, dtype=torch.float32, device=flat.device)
         _lib.check(L.as_artspeech_fwd(C.byref(dims), _lib.ptr(flat), _lib.ptr(tokens), tokens.stride(0),
-                                      _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(ws), int(train),
+                                      _lib.ptr(lengths_dev), B, T, _lib.ptr(out), _lib.ptr(ws), int(train or opts is not None),
                                       C.byref(opts) if opts is not None else None, _lib.stream_ptr()), "as_artspeech_fwd")
         # nn.Embedding raises for ids outside [0, V) (reference models.py:135); the kernels clamp them (memory safety) and
         # count them in the first word of the workspace -- read here, where the drop-in path may synchronise

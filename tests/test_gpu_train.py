@@ -323,6 +323,12 @@ def test_simple_artspeech_dropout_training_mode(dev):
         out_eval = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
     o_eval, _ = O.simple_artspeech_fwd(sd, x, A)
     assert np.abs(out_eval.cpu().numpy() - o_eval).max() < 1e-5
+    # dropout follows the MODULE's mode, not grad mode (nn.Dropout drops under torch.no_grad() while model.training is set)
+    model.train()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        out_ng = model(torch.from_numpy(x).to(dev), torch.from_numpy(lengths))
+    assert torch.equal(out_ng, out.detach())          # same seed, same mask as the graded call above
 
 
 def test_evaluation_entry_points_write_reference_outputs(dev, tmp_path):
