@@ -332,9 +332,12 @@ def main():
         psteps = min(args.steps, 20)
         L.as_profile_reset()  # same configuration as the timed region (side-stream overlap on)
         L.as_profile_enable(1)
+        step.flush()
+        use_dist, step.use_dist = step.use_dist, False   # rank 0 alone runs this pass: no collectives in it
         for i in range(psteps):   # whole steps: the pipelined schedule carries work across the step boundary
             step.step(tokens, lengths_dev, targets, scale)
         step.flush()
+        step.use_dist = use_dist
         torch.cuda.synchronize()
         L.as_profile_enable(0)
         buf = C.create_string_buffer(1 << 16)
@@ -436,6 +439,9 @@ def main():
                 p_["workload"] = ("transformer forward -> tract variables -> area function + resampling -> DeepSpeech2 scorer "
                                   "top-1, B=32 T=200, one GPU (configs[4] shards utterances over 8)")
                 extras["pipeline_c5_1gpu"] = p_
+                # the three small kernels north_star names besides the recurrence, alone, HIP-event timed: GB/s vs 8 TB/s
+                import bench_metrics_kernels
+                extras["metrics_kernels"] = bench_metrics_kernels.main(iters=30, log=log)
             except Exception as exc:  # the headline must survive a failure of the extras
                 extras["extras_error"] = f"{type(exc).__name__}: {exc}"
                 log(f"extras failed: {extras['extras_error']}")

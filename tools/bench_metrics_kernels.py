@@ -23,9 +23,10 @@ ARTS = sorted(["arytenoid-cartilage", "epiglottis", "lower-incisor", "lower-lip"
                "tongue", "upper-incisor", "upper-lip", "vocal-folds"])
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 50
-    json_path = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+def main(iters=None, json_path=None, log=print):
+    if iters is None:
+        iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 50
+        json_path = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
     L = _lib.lib()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -70,7 +71,7 @@ def main():
     cases["as_evenly_spaced_fx (resample_kernel)"] = (run_resample, frames * (2 * NW * 8 + 2 * NS * 4))
 
     report = {}
-    print(f"--- B={B} T={T} ({frames} frames), {iters} launches each, HIP events on the launch stream", flush=True)
+    log(f"--- B={B} T={T} ({frames} frames), {iters} launches each, HIP events on the launch stream")
     for name, (fn, nbytes) in cases.items():
         for _ in range(5):
             fn()
@@ -85,7 +86,7 @@ def main():
         gbs = nbytes / (us * 1e-6) / 1e9
         report[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "achieved_GBs": round(gbs, 1),
                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "frames_per_s": round(frames / (us * 1e-6), 0)}
-        print(f"{name:42s} {us:8.2f} us   {nbytes / 1e6:7.2f} MB   {gbs:8.1f} GB/s   {gbs / HBM_PEAK_GBS:6.3f} of 8 TB/s", flush=True)
+        log(f"{name:42s} {us:8.2f} us   {nbytes / 1e6:7.2f} MB   {gbs:8.1f} GB/s   {gbs / HBM_PEAK_GBS:6.3f} of 8 TB/s")
     assert torch.isfinite(p2cp).all() and torch.isfinite(tv_v).all() and torch.isfinite(dists).all() and torch.isfinite(res).all()
     if json_path:
         with open(json_path, "w") as f:
