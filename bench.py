@@ -71,11 +71,11 @@ def gemm_flops(rows):
 # GEMM phases grouped by the kernels that run them, named as rocprofv3 prints them (profiles/r02_kernel_stats.csv).
 # head.gemm1/2 and headb.dx3/2 are the fused Linear + LayerNorm kernels: their time includes the LayerNorm epilogue.
 GEMM_FAMILIES = {
-    "forward (C = act(A.B^T + b)): lin_f32_kernel<64, true, 1> [head Linear 1, 2 + ReLU + LayerNorm] + gemm_f32_kernel<*, *, true, true, true>":
+    "forward (C = act(A.B^T + b)): lin_f32_kernel<64, true, 1> [head Linear 1, 2 + ReLU + LayerNorm] + lin_out_kernel [output layer; its time includes the fused criterion epilogue] + gemm_f32_kernel<*, *, true, true, true>":
         ["gru.table0", "gru.xproj1", "trunk.linear", "head.gemm1", "head.gemm2", "head.gemm3"],
     "input gradients (C = A.B): lin_f32_kernel<64, false, 2> [head dx 3, 2 + LayerNorm/ReLU backward] + gemm_f32_kernel<*, *, true, false, true>":
         ["headb.dx3", "headb.dx2", "headb.dx1", "trunkb.dx", "grub.dx1", "grub.demb"],
-    "weight gradients (C = A^T.B): wgrad_f32_kernel<*, 32> [heads] + gemm_f32_kernel<64, 64, false, false, true> [GRU, trunk]":
+    "weight gradients (C = A^T.B): wgrad_f32_kernel<256, 32>(WgradMulti) [heads + trunk: two multi-problem launches, one of them a step late] + gemm_f32_kernel<64, 64, false, false, true> [GRU]":
         ["headb.dw_fused", "headb.dw31", "headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
 }
 
