@@ -595,12 +595,16 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     const int V = d->vocab, E = d->embed, H = d->hidden, R = B * T;
     // the weight folds depend on the parameters only: run them on the side stream beside the recurrences
     StreamState* sd = d->simple ? nullptr : side_for(st);
-    if (opts && opts->fold_wait_event) {   // a deferred parameter update (as_opts) must land before the heads' weights are folded
+    const bool late = opts && opts->fold_wait_event;
+    if (late) {   // a deferred parameter update (as_opts) must land before the heads' weights are folded
         const hipError_t e = hipStreamWaitEvent(sd ? sd->side : st, (hipEvent_t)opts->fold_wait_event, 0);
         AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_fwd: cannot wait for fold_wait_event: %s", hipGetErrorString(e));
     }
     if (sd) {
-        AS_TRY(fork_to(st, sd->side, sd->fork[0]));
+        // the folds read the parameters: behind everything `st` holds (the previous optimizer step).  With a deferred update
+        // the event above already stands behind that (the update was enqueued after it), and an event record on `st` is a
+        // barrier packet in front of the step's first kernel: skipped then
+        if (!late) AS_TRY(fork_to(st, sd->side, sd->fork[0]));
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, sd->side));
         AS_TRY(as_count_bad_tokens(tokens, tok_stride, T, R, V, reinterpret_cast<int*>(ws + w.tokflag), sd->side));
         if (hipEventRecord(sd->join, sd->side) != hipSuccess) {
@@ -613,7 +617,10 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
-        AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));
+        if ((long)V * E <= 16384)   // the step's first kernel, on its critical path: a small dedicated kernel (rowops.hip)
+            AS_STEP("gru.table0", st, as_token_table(P + L.embedding, P + L.w_ih[0], P + L.b_ih[0], V, 6 * H, E, ws + w.tab0, st));
+        else
+            AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));
         AS_STEP("gru.fwd_l0", st, as_gru_bidir_fwd_tokens(ws + w.tab0, tokens, tok_stride, V, P + L.w_hh[0], P + L.b_hh[0], lengths, B, T, H, ws + w.y0,
                                 train ? ws + w.g0 : nullptr, st));
         const float* l1_in = ws + w.y0;
@@ -743,7 +750,10 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
     if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
-    if (s3 != s2) AS_TRY(fork_to(st, s3, sd->fork2[1]));
+    if (s3 != s2) {   // ONE record on `st` for both side streams (every event record is a barrier packet on the critical stream)
+        const hipError_t e = hipStreamWaitEvent(s3, sd->fork[1], 0);
+        AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_bwd: stream wait failed: %s", hipGetErrorString(e));
+    }
     // layer 0 sits under the token table: the recurrence keeps per-token sums of its input-side gate gradients in LDS and
     // leaves B tables [V][6H] where dgi0 would have gone (V <= T: they fit), so there is no dgi0 and no segmented-sum
     // pass; else dgi0 + as_token_segsum below

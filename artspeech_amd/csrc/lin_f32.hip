@@ -44,7 +44,7 @@ struct LinK {
 #ifdef AS_DIAG
     int stagger;
 #else
-    static constexpr int stagger = 0;
+    static constexpr int stagger = 1;   // product: the second workgroup of every CU's first fill starts half a tile late
 #endif
     unsigned long long* dbg; long dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps), normally null
 #ifdef AS_DIAG
@@ -174,8 +174,14 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     // Two workgroups share a CU and would run in lockstep (same start, same tile time): both in their prologue, both in
     // their main loop, both in their epilogue -- nothing overlaps.  The second wave of the first fill (blocks 256..511 under
     // round-robin dispatch: speed only) starts half a tile late; every later workgroup inherits the phase of the slot it takes.
-    if (g.stagger && blockIdx.x >= 256 && blockIdx.x < 512) {
+    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
         for (int i = 0; i < nk * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
+    }
+    // diagnostic (AS_LIN_STAGGER < 0): de-phase the XCDs instead -- the first-fill workgroups of XCD x start x * |stagger| / 8
+    // of a 16-k-tile main loop late, so that the epilogues' store bursts of the eight dies do not coincide chip-wide
+    if (g.stagger < 0 && blockIdx.x < 512) {
+        const int steps = (int)(blockIdx.x & 7) * (-g.stagger) * 2;          // x * |stagger| * 2 sleeps of 1024 cycles
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const int swz = (l31 >> 2) & 3;   // rows i * 32 + l31 and wave * 32 + l31 share it (32 = 0 mod 16)
     // two k-tiles in flight; the older one is retired with vmcnt(3).  (A 2-slot ring with three workgroups per CU was no
@@ -561,7 +567,7 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
 #ifdef AS_DIAG
     static const int abl = AS_DIAG_INT("AS_LIN_ABL", 0);
     k.abl = abl;
-    static const int stagger = AS_DIAG_INT("AS_LIN_STAGGER", 0);  // measured: no gain
+    static const int stagger = AS_DIAG_INT("AS_LIN_STAGGER", 1);  // round 3 (pipelined main loop): 1 = -3 % on Linear 2 / dx2; < 0: XCD de-phasing (slower)
     k.stagger = stagger;
 #endif
     k.dbg = g_dbg; k.dbg_max = g_dbg_max;

@@ -19,6 +19,8 @@ int as_unfold3(const float* const dWf[3], const float* const dbf[3], const float
 int as_token_segsum(const float* x, const int64_t* tokens, long tok_stride, int T, long rows, int C, int V, float* out,
                     hipStream_t st, float* scratch = nullptr, long scratch_floats = 0);
 // dW [C][E] = dtab^T . emb, db [C] = column sums of dtab, demb [V][E] = dtab . W   (dtab [V][C], emb [V][E], W [C][E])
+// tab [V][C] = emb [V][E] . W [C][E]^T + bias [C]   (V * E floats must fit the LDS: the caller checks V * E <= 16384)
+int as_token_table(const float* emb, const float* W, const float* bias, int V, int C, int E, float* tab, hipStream_t st);
 int as_emb_grads(const float* dtab, const float* emb, const float* W, int V, int C, int E, float* dW, float* db, float* demb,
                  hipStream_t st);
 // V > 0: ids are clamped into [0, V) (the table has V rows)

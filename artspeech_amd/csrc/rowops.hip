@@ -422,6 +422,38 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int c = threadIdx.x & 63; c < C; c += 64) out[m * C + c] = table[v * C + c];
 }
 
+// ---- token table of the layer-0 input projections: tab[v][c] = b[c] + sum_e emb[v][e] * W[c][e]  (V x C outputs, E <= 256).
+// It is the FIRST kernel of every forward and the recurrence waits for it; as a general-GEMM launch (12 workgroups walking
+// four dependent k-tiles) it took 10 us for 4.4 MFLOP.  Here: one workgroup per (64 output columns, 4 table rows) -- 144
+// workgroups at V = 45, C = 768 --, its four embedding rows and 64 weight rows staged in LDS once (coalesced), one output per thread.
+__global__ __launch_bounds__(256) void token_table_kernel(const float* __restrict__ emb, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int V, int C, int E,
+                                                          float* __restrict__ tab) {
+    extern __shared__ __attribute__((aligned(16))) float tt_s[];   // four emb rows [4][E], then this workgroup's 64 weight rows [64][E + 1]
+    float* emb_s = tt_s;
+    float* w_s = tt_s + 4 * E;
+    const int c0 = blockIdx.x * 64;
+    const int v0 = blockIdx.y * 4;                         // this workgroup's four table rows (one per wave)
+    for (int i = threadIdx.x; i < 4 * E; i += 256) emb_s[i] = v0 + i / E < V ? emb[(long)v0 * E + i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * E; i += 256) {      // coalesced: consecutive threads read consecutive floats of a row
+        const int r = i / E, e = i - r * E;
+        w_s[r * (E + 1) + e] = c0 + r < C ? W[(long)(c0 + r) * E + e] : 0.f;
+    }
+    __syncthreads();
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;   // a thread per (column, one of 4 row groups)
+    const int c = c0 + cl;
+    if (c >= C) return;
+    const float bc = bias[c];
+    const float* wr = w_s + cl * (E + 1);                      // row stride E + 1: the 64 lanes hit 64 different banks
+    const int v = v0 + rg;
+    if (v >= V) return;
+    const float* er = emb_s + rg * E;                           // wave-uniform: broadcast reads
+    float acc = bc;
+#pragma unroll 8
+    for (int e = 0; e < E; ++e) acc = fmaf(er[e], wr[e], acc);
+    tab[(long)v * C + c] = acc;
+}
+
 // ---- batched collate on the device: out[b][t][:] = t < len[b] ? src[first[b] + t][:] : pad  (pad_sequence of a batch whose
 // unpadded utterances lie back to back in one resident buffer; dataset.py:27-65 of the reference does this on the host)
 template <typename T>
@@ -796,6 +828,12 @@ int as_gather_rows(const float* table, const int64_t* tokens, long tok_stride, i
                    hipStream_t st, int V) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, table, tokens, tok_stride, T, rows, C, out, V);
     AS_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+int as_token_table(const float* emb, const float* W, const float* bias, int V, int C, int E, float* tab, hipStream_t st) {
+    hipLaunchKernelGGL(token_table_kernel, dim3(as_cdiv(C, 64), as_cdiv(V, 4)), dim3(256), ((size_t)4 * E + 64 * (E + 1)) * sizeof(float), st, emb,
+                       W, bias, V, C, E, tab);
+    AS_LAUNCH_CHECK("token_table");
     return 0;
 }
 int as_count_bad_tokens(const int64_t* tokens, long tok_stride, int T, long rows, int V, int* count, hipStream_t st) {

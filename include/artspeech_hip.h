@@ -98,7 +98,8 @@ typedef struct as_opts {
        step's forward recurrences (64 of 256 CUs busy), followed by that slice's all-reduce and Adam update.
        as_artspeech_fwd with fold_wait_event != NULL (a hipEvent_t) makes the stream that folds the head weights wait for
        that event first (the deferred update must be in place before the heads read their parameters); the recurrences do
-       not wait.  Same arithmetic on the same operands as the unpipelined step: bit-identical parameters. */
+       not wait.  The event must stand BEHIND the previous optimizer step on `stream` (the engine enqueues the deferred update
+       after a wait for `stream`): the forward then relies on it alone to order its weight folds.  Same arithmetic on the same operands as the unpipelined step: bit-identical parameters. */
     int32_t defer_dw2;
     void* fold_wait_event;
     /* as_artspeech_fwd (training engine): the criterion of train_phoneme_to_articulation.py:86-90 fused into the epilogue of

@@ -1,0 +1,8 @@
+#!/bin/bash
+source tools/gpu_steps.sh
+out=gpurun_out/r03k; mkdir -p $out
+export ARTSPEECH_DIAG_LIB=1
+for sg in 0 -1 -2 -4 1; do
+  step 120 $out/heads_s$sg.log env AS_LIN_STAGGER=$sg python tools/bench_heads.py 20
+  echo "stagger $sg: $(grep -h 'gemm1\|gemm2\|dx3\|dx2' $out/heads_s$sg.log | tr '\n' ' ')"
+done
