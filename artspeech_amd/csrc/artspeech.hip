@@ -628,7 +628,25 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
             AS_STEP("gru.dropout", st, as_dropout(ws + w.y0, ws + w.y0d, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
             l1_in = ws + w.y0d;
         }
-        AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
+        {
+            // input projection of GRU layer 1: [R][2H] . [6H][2H]^T + b.  (diagnostic build, AS_XPROJ_LIN = 64 | 32: the LDS-DMA
+            // kernel of the head layers on three 256-column blocks instead of the general kernel's 64 x 64 tiles)
+            static const int xproj_lin = AS_DIAG_INT("AS_XPROJ_LIN", 0);
+            int took = 0;
+            if (xproj_lin && 6 * H % 256 == 0) {
+                as_lin l{};
+                l.A = l1_in; l.lda = 2 * H; l.a_batch = 0;
+                l.B = P + L.w_ih[1]; l.ldb = 2 * H; l.b_batch = 256L * 2 * H; l.b_kc = 1;
+                l.C = ws + w.xp1; l.ldc = 6 * H; l.c_batch = 256;
+                l.bias = P + L.b_ih[1]; l.bias_batch = 256;
+                l.M = R; l.N = 256; l.K = 2 * H; l.batch = 6 * H / 256; l.tile_rows = xproj_lin;
+                AS_PROF("gru.xproj1", st);
+                took = as_lin_try(&l, st);
+                AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
+            }
+            if (!took)
+                AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
+        }
         AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
                                 train ? ws + w.g1 : nullptr, st));
         AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
@@ -731,14 +749,14 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     {
         // input gradient of GRU layer 1: [R][6H] . [6H][2H].  (diagnostic build, AS_DX1_LIN: the LDS-DMA kernel of the head
         // layers on 32-row x 256-column tiles instead of the general kernel's 64 x 64 tiles + in-kernel split-K)
-        static const bool dx1_lin = AS_DIAG_SET("AS_DX1_LIN");
+        static const int dx1_lin = AS_DIAG_INT("AS_DX1_LIN", 0);   // 64 | 32 = tile rows
         int took = 0;
         if (dx1_lin && 2 * H == 256) {
             as_lin l{};
             l.A = ws + w.dgi1; l.lda = 6 * H;
             l.B = P + L.w_ih[1]; l.ldb = 2 * H; l.b_kc = 0;
             l.C = ws + w.dy0; l.ldc = 2 * H;
-            l.M = R; l.N = 2 * H; l.K = 6 * H; l.batch = 1;
+            l.M = R; l.N = 2 * H; l.K = 6 * H; l.batch = 1; l.tile_rows = dx1_lin;
             AS_PROF("grub.dx1", st);
             took = as_lin_try(&l, st);
             AS_REQUIRE(took >= 0, took, "grub.dx1: launch failed");

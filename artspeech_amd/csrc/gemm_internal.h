@@ -31,6 +31,7 @@ struct as_lin {
     int M, N, K, ka_valid, batch, act, epi;
     float* rstd; unsigned long long* bits;
     const float* xhat; long ldx, x_batch; const float* rstd_in; const unsigned long long* bits_in;
+    int tile_rows;   // 0 = the mixed tile list (64-row tiles that fill whole rounds, then 32-row tiles); 64 / 32 = that size only
 };
 int as_lin_try(const as_lin* a, hipStream_t st);
 

@@ -474,6 +474,9 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
             float4 gv[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) gv[c] = gq[c * 16 + r];
+            // (Round 3 tried ONE no-return LDS atomic, ds_add_f32, issued as soon as vi exists, in place of the read + write:
+            // 2508 instead of 1415 cycles per step -- a 64-lane float atomic occupies the LDS for about a thousand cycles
+            // and the step's barrier waits for it.  Not kept.)
             // TOK: the table word of this step's token is read BEHIND the gate reads (LDS answers in order) and written
             // back after the FMAs below: its round trip hides under them instead of standing before them.  The fourth lane
             // of a unit (a duplicate of the n plane) works on a private dummy word, so no lane is masked off.

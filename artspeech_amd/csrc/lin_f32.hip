@@ -41,6 +41,7 @@ struct LinK {
     const float* bias; long bias_batch;
     int M, N, K, ka_valid, batch, act;
     int n_big, big_per_batch, big_per_batch_rows, small_per_batch;   // tiles of 64 rows first, then tiles of 32 rows (see launch())
+    int tile_rows;
 #ifdef AS_DIAG
     int stagger;
 #else
@@ -523,7 +524,8 @@ int launch(const LinK& k, hipStream_t st) {
     const long rounds = units / slots;
     static const bool all_big = AS_DIAG_SET("AS_LIN_ALLBIG");  // ablation: 64-row tiles only (+ a ragged end)
     int x = (int)(rounds * slots / k.batch);                    // 64-row tiles per head that fill whole rounds
-    if (x > k.M / 64 || all_big) x = k.M / 64;
+    if (x > k.M / 64 || all_big || k.tile_rows == 64) x = k.M / 64;
+    if (k.tile_rows == 32) x = 0;
     const int rest = k.M - x * 64;
     kk.big_per_batch = x > 0 ? x : 1;
     kk.big_per_batch_rows = x * 64;
@@ -563,6 +565,7 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     k.C = a->C; k.ldc = a->ldc; k.c_batch = a->c_batch;
     k.bias = a->bias; k.bias_batch = a->bias_batch;
     k.M = a->M; k.N = a->N; k.K = a->K; k.ka_valid = a->ka_valid > 0 ? a->ka_valid : a->K; k.batch = a->batch; k.act = a->act;
+    k.tile_rows = a->tile_rows;
     k.eps = 1e-5f;
 #ifdef AS_DIAG
     static const int abl = AS_DIAG_INT("AS_LIN_ABL", 0);
