@@ -45,7 +45,7 @@ struct LinK {
 #ifdef AS_DIAG
     int stagger;
 #else
-    static constexpr int stagger = 1;   // product: the second workgroup of every CU's first fill starts half a tile late
+    static constexpr int stagger = 0;
 #endif
     unsigned long long* dbg; long dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps), normally null
 #ifdef AS_DIAG
@@ -98,12 +98,14 @@ __device__ __forceinline__ void lds_barrier() {  // LDS hazards only: unlike __s
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BM, bool B_KC, int EPI>
-__global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
+// NB ring slots: 3 (two k-tiles in flight, 60 KB: two workgroups per CU) or 2 (one in flight, 40 KB: three per CU; diagnostic)
+template <int BM, bool B_KC, int EPI, int NB = NBUF>
+__global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
     constexpr int TM = BM / 32;
     constexpr int TILE = BK * (BM + BN);
     constexpr int PA_TOTAL = BM / 16;    // 1-KiB DMA pieces of the A tile (16 rows x 16 k each)
-    constexpr int RING = NBUF * TILE, EPIT = 32 * BN;
+    constexpr int RING = NB * TILE, EPIT = 32 * BN;
+    constexpr int AHEADT = NB - 1;       // k-tiles in flight besides the one being multiplied
     __shared__ __attribute__((aligned(16))) float smem[RING > EPIT ? RING : EPIT];
 
     // tile list: the 64-row tiles of every head first, then 32-row tiles over the remaining rows of every head
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     }
     const unsigned smem_base = lds_addr(smem);
     auto issue = [&](int kt) {
-        const unsigned base = smem_base + (unsigned)((kt % NBUF) * TILE) * 4u;
+        const unsigned base = smem_base + (unsigned)((kt % NB) * TILE) * 4u;
         const int k0 = kt * BK;
         const bool ok = k0 + a_gc + 4 <= g.ka_valid;
         glds16(a_src + (ok ? k0 : -a_gc), base + (unsigned)(pa * 1024));
@@ -175,8 +177,10 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     // Two workgroups share a CU and would run in lockstep (same start, same tile time): both in their prologue, both in
     // their main loop, both in their epilogue -- nothing overlaps.  The second wave of the first fill (blocks 256..511 under
     // round-robin dispatch: speed only) starts half a tile late; every later workgroup inherits the phase of the slot it takes.
-    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < nk * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
+    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 256 * NB) {
+        // NB = 3 (two per CU): the second starts half a tile late; NB = 2 (three per CU): a third and two thirds of a tile
+        const int steps = NB == 3 ? nk * g.stagger : (int)(blockIdx.x >> 8) * nk * g.stagger * 2 / 3;
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
     }
     // diagnostic (AS_LIN_STAGGER < 0): de-phase the XCDs instead -- the first-fill workgroups of XCD x start x * |stagger| / 8
     // of a 16-k-tile main loop late, so that the epilogues' store bursts of the eight dies do not coincide chip-wide
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     // two k-tiles in flight; the older one is retired with vmcnt(3).  (A 2-slot ring with three workgroups per CU was no
     // faster: 108-118 us against 108-114 for head GEMM 2.)
     issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (AHEADT > 1 && nk > 1) issue(1);
+    if (AHEADT > 1 && nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (stamp) g.dbg[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     // with all eight waves waiting for their first fragments, ~10 % of a 2048-cycle tile with the pipe idle).
     struct Frag { float4 av[TM]; float bv[4]; };
     auto load = [&](Frag& f, int kt_, int cc) {
-        const float* tile = smem + (kt_ % NBUF) * TILE;
+        const float* tile = smem + (kt_ % NB) * TILE;
         const float* a_s = tile + l31 * BK;
         const float* b_s = tile + BK * BM;
         const int slot = ((2 * cc + lh) ^ swz) * 4;
@@ -230,14 +234,14 @@ __global__ __launch_bounds__(NT, 4) void lin_f32_kernel(LinK g) {
     Frag f0, f1;
     load(f0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) issue(kt + 2);
+        if (kt + AHEADT < nk) issue(kt + AHEADT);
         load(f1, kt, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(f0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (AHEADT > 1 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot kt % 3 are in registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot kt % NB are in registers
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < nk) load(f0, kt + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -519,7 +523,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <bool B_KC, int EPI>
 int launch(const LinK& k, hipStream_t st) {
     LinK kk = k;
-    constexpr int slots = 512;
+    static const int nbuf = AS_DIAG_INT("AS_LIN_NBUF", 3);      // 2: two ring slots, three workgroups per CU (diagnostic)
+    const int slots = nbuf == 2 ? 768 : 512;
     const long units = (long)as_cdiv(k.M, 64) * k.batch;      // work in 64-row tiles
     const long rounds = units / slots;
     static const bool all_big = AS_DIAG_SET("AS_LIN_ALLBIG");  // ablation: 64-row tiles only (+ a ragged end)
@@ -533,6 +538,10 @@ int launch(const LinK& k, hipStream_t st) {
     kk.small_per_batch = as_cdiv(rest, 32);
     const long total = (long)kk.n_big + (long)kk.small_per_batch * k.batch;
     if (kk.small_per_batch == 0) kk.small_per_batch = 1;
+#ifdef AS_DIAG
+    if (nbuf == 2) hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI, 2>), dim3((unsigned)total), dim3(NT), 0, st, kk);
+    else
+#endif
     hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI>), dim3((unsigned)total), dim3(NT), 0, st, kk);
     AS_LAUNCH_CHECK("as_lin_f32");
     return 0;
@@ -570,7 +579,9 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
 #ifdef AS_DIAG
     static const int abl = AS_DIAG_INT("AS_LIN_ABL", 0);
     k.abl = abl;
-    static const int stagger = AS_DIAG_INT("AS_LIN_STAGGER", 1);  // round 3 (pipelined main loop): 1 = -3 % on Linear 2 / dx2; < 0: XCD de-phasing (slower)
+    // round 3: 1 (second workgroup of a CU half a tile late) is -3 % on one box and +3 % on the next: noise; < 0 = XCD de-phasing
+    // (strictly slower); with AS_LIN_NBUF=2 (three workgroups per CU on a 2-slot ring) thirds of a tile: no change either
+    static const int stagger = AS_DIAG_INT("AS_LIN_STAGGER", 0);
     k.stagger = stagger;
 #endif
     k.dbg = g_dbg; k.dbg_max = g_dbg_max;
