@@ -149,14 +149,21 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
         }
     }
     const unsigned smem_base = lds_addr(smem);
-    auto issue = [&](int kt) {
+    // piece 0 = this wave's A piece, pieces 1, 2 = its two B pieces of k-tile kt
+    auto issue_piece = [&](int kt, int piece) {
         const unsigned base = smem_base + (unsigned)((kt % NB) * TILE) * 4u;
         const int k0 = kt * BK;
-        const bool ok = k0 + a_gc + 4 <= g.ka_valid;
-        glds16(a_src + (ok ? k0 : -a_gc), base + (unsigned)(pa * 1024));
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+        if (piece == 0) {
+            const bool ok = k0 + a_gc + 4 <= g.ka_valid;
+            glds16(a_src + (ok ? k0 : -a_gc), base + (unsigned)(pa * 1024));
+        } else {
+            const int j = piece - 1;
             glds16(b_src[j] + (B_KC ? (long)k0 : (long)k0 * g.ldb), base + (unsigned)((BK * BM + (wave * 2 + j) * 256) * 4));
+        }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) issue_piece(kt, pc);
     };
 
     f32x16 acc[TM];
@@ -177,10 +184,21 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
     // Two workgroups share a CU and would run in lockstep (same start, same tile time): both in their prologue, both in
     // their main loop, both in their epilogue -- nothing overlaps.  The second wave of the first fill (blocks 256..511 under
     // round-robin dispatch: speed only) starts half a tile late; every later workgroup inherits the phase of the slot it takes.
-    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 256 * NB) {
+    if (g.stagger > 0 && g.stagger < 10 && blockIdx.x >= 256 && blockIdx.x < 256 * NB) {
         // NB = 3 (two per CU): the second starts half a tile late; NB = 2 (three per CU): a third and two thirds of a tile
         const int steps = NB == 3 ? nk * g.stagger : (int)(blockIdx.x >> 8) * nk * g.stagger * 2 / 3;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles = half a k-tile of MFMAs
+    }
+    // diagnostic (AS_LIN_STAGGER >= 10): the same delay, but for the workgroup that really is the SECOND tenant of its CU --
+    // told by the wave slot its first wave got on its SIMD (HW_ID.wave_id >= 2: slots 0, 1 belong to the first tenant) -- instead
+    // of by block index (the dispatcher need not place blocks b and b + 256 on one CU)
+    if (g.stagger >= 10 && blockIdx.x < 512) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID[3:0] = wave slot on the SIMD
+        __shared__ int second;
+        if (tid == 0) second = slot >= 2;
+        __syncthreads();
+        if (second)
+            for (int i = 0; i < nk * (g.stagger - 9); ++i) __builtin_amdgcn_s_sleep(16);
     }
     // diagnostic (AS_LIN_STAGGER < 0): de-phase the XCDs instead -- the first-fill workgroups of XCD x start x * |stagger| / 8
     // of a 16-k-tile main loop late, so that the epilogues' store bursts of the eight dies do not coincide chip-wide
@@ -218,7 +236,11 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
             for (int j = 0; j < 4; ++j) f.bv[j] = b_s[(cc * 8 + 4 * lh + j) * BN + wave * 32 + l31];
         }
     };
-    auto mma = [&](const Frag& f) {
+    // dma_kt >= 0: the three DMA pieces of k-tile dma_kt are issued BETWEEN the MFMAs (one after each of the first three
+    // k-steps): an LDS-DMA costs the issuing wave ~60-180 cycles of instruction issue, and as a block at the top of the tile
+    // -- every wave of the workgroup at the same moment, right behind the barrier -- those cycles were matrix-pipe idle
+    // time; behind an MFMA they run while the pipe works on it.
+    auto mma = [&](const Frag& f, int dma_kt) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -228,16 +250,20 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.bv[j], acc[i], 0, 0, 0);
                 }
             }
+            if (j < 3 && dma_kt >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(dma_kt, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     static_assert(BK == 16, "two fragment groups per k-tile");
     Frag f0, f1;
     load(f0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + AHEADT < nk) issue(kt + AHEADT);
         load(f1, kt, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
+        mma(f0, kt + AHEADT < nk ? kt + AHEADT : -1);
         __builtin_amdgcn_sched_barrier(0);
         if (AHEADT > 1 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < nk) load(f0, kt + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
+        mma(f1, -1);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (stamp) g.dbg[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();

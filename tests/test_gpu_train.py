@@ -383,6 +383,7 @@ def test_overlapped_gradient_all_reduce_equals_single_all_reduce(dev):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("overlap == plain all-reduce: True") == 2
+    assert res.stdout.count("pipelined == plain: True") == 2     # the pipelined engine's late all-reduce under data parallelism
     # transformer trainer: all-reduce hooks fired during the backward == full-batch gradients
     cmd[-1] = os.path.join(ROOT, "tools", "check_dp_transformer.py")
     cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
@@ -440,15 +441,20 @@ def test_out_of_range_token_ids_raise_like_nn_embedding(dev, bad):
     assert np.isfinite(step.loss_value())
 
 
-def test_pipelined_engine_is_bit_identical_to_the_unpipelined_one(dev):
+@pytest.mark.parametrize("shape", ["small", "configs1"])
+def test_pipelined_engine_is_bit_identical_to_the_unpipelined_one(dev, shape):
     """TrainStep(pipeline=True) carries the weight gradient + Adam update of the heads' second Linear into the next step's
     forward (beside its recurrences).  After flush() the parameters, both Adam moments and every step's loss must equal the
     unpipelined engine's BIT FOR BIT: same operands, same arithmetic, another schedule.  B*T is a multiple of 32 and >= 512 so
     that the fused weight-gradient launches are the ones exercised; ragged lengths; batches change from step to step."""
     from artspeech_amd.engine import TrainStep
     from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
-    V, A, B, T = 45, 3, 8, 96
-    lengths = torch.tensor([96, 90, 77, 64, 40, 33, 8, 1], dtype=torch.int32)
+    if shape == "small":
+        V, A, B, T = 45, 3, 8, 96
+        lengths = torch.tensor([96, 90, 77, 64, 40, 33, 8, 1], dtype=torch.int32)
+    else:       # BASELINE configs[1]: B = 32, T = 200, A = 11, ragged
+        V, A, B, T = 45, 11, 32, 200
+        lengths = torch.linspace(200, 60, 32).int()
     scale = 1.0 / (float(lengths.sum()) * A * 50)
     g = torch.Generator().manual_seed(3)
     batches = []

@@ -19,7 +19,9 @@ torch.cuda.set_device(dev)
 dist.init_process_group(backend, rank=rank, world_size=world)
 B, T, A, N, V = 6, 40, 3, 10, 17
 results = []
-for overlap in (True, False):
+# third case (round 3): the PIPELINED engine -- the layer-2 weight gradient, its all-reduce and its Adam slice run one step
+# late on a side stream -- must leave the same parameters after flush() as the plain one
+for overlap, pipeline in ((True, False), (False, False), (False, True)):
     torch.manual_seed(0)
     model = ArtSpeech(V, A, embed_dim=16, hidden_size=32, n_samples=N).to(dev)
     g = torch.Generator().manual_seed(100 + rank)
@@ -29,7 +31,8 @@ for overlap in (True, False):
     targets = torch.rand(B, T, A, 2, N, generator=g).to(dev)
     n_valid = torch.tensor([int(lengths.sum())], device=dev)
     dist.all_reduce(n_valid)
-    step = TrainStep(model, B, T, lr=1e-3)
+    step = TrainStep(model, B, T, lr=1e-3, pipeline=pipeline)
+    assert step.pipeline == pipeline
     if os.environ.get("FORCE_DIST"):  # exercise the collective code path on a single rank (RCCL API usage under streams)
         step.use_dist = True
     step.ar_overlap = overlap and step.use_dist
@@ -37,9 +40,13 @@ for overlap in (True, False):
         step.comm_stream = torch.cuda.Stream(device=dev)
     for _ in range(4):
         step.step(tokens, lengths.to(dev), targets, 1.0 / (int(n_valid) * A * N))
+    step.flush()
     torch.cuda.synchronize()
     results.append((model.flat.data.clone(), step.grads.clone(), float(step.loss)))
 same = torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+same_pipe = torch.equal(results[2][0], results[1][0]) and torch.equal(results[2][1], results[1][1])
+print(f"rank {rank}/{world}: pipelined == plain: {same_pipe}", flush=True)
+same = same and same_pipe
 # every rank must hold the same parameters after the synchronised updates
 ref = results[0][0].clone()
 dist.broadcast(ref, src=0)
