@@ -49,7 +49,10 @@ class Gemm(C.Structure):
                 ("b_kshift", C.c_int32), ("b_kT", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64), ("colsum", C.c_void_p),
                 ("colsum_batch", C.c_int64), ("a_off", C.c_void_p), ("b_off", C.c_void_p), ("c_off", C.c_void_p),
-                ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32), ("cu_budget", C.c_int32)]
+                ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32), ("cu_budget", C.c_int32),
+                ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_batch", C.c_int64), ("res_off", C.c_void_p),
+                ("mask", C.c_void_p), ("mask_ld", C.c_int64), ("mask_batch", C.c_int64),
+                ("k_seg", C.c_int32), ("a_seg_off", C.c_void_p), ("b_seg_off", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

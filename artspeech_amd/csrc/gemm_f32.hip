@@ -38,6 +38,11 @@ struct GemmK {
     float* colsum; long colsum_batch;
     // grouped batches: per-batch element offsets (device arrays) override the linear batch strides
     const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
+    // optional epilogue operands: C = mask > 0 ? act(acc + bias + res) : 0 (as_gemm.res / .mask)
+    const float* res; long res_ld, res_batch; const long* res_off;
+    const float* mask; long mask_ld, mask_batch;
+    // optional segmented reduction (as_gemm.k_seg): per (batch, segment) element offsets of the A rows and the B panel
+    int k_seg; const long* a_seg_off; const long* b_seg_off;
 };
 
 // device-scope accesses for data handed between workgroups of one launch (they may sit on different XCDs, whose L2s are not
@@ -158,7 +163,9 @@ __device__ __forceinline__ float frag(const float* __restrict__ s, int i, int k)
     return KC ? s[i * (BK + 1) + k] : s[k * BI + i];
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
+// EXT: the instantiation that knows the optional epilogue operands (res / mask) and the segmented reduction; the plain one
+// carries neither (its register budget at three workgroups per CU has no room for them).
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST, bool EXT = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_kernel(GemmK g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     // ONE LDS image per operand: the next tile waits in registers while this one is consumed, so a
@@ -205,13 +212,27 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
     if (work >= total) return;
     Work w = decode(work);
     float4 ra[BM / 32], rb[BN / 32];
-    tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
-    tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, w.kshift, g.b_kT, tid);
+    // operand tiles of work item x at reduction index k0 -> registers.  Segmented reduction: the segment's own A rows / B
+    // panel, k counted from the segment's start (k_seg is a multiple of BK: a k-tile never straddles two segments).
+    auto load_tiles = [&](const Work& x, int k0) {
+        const float* Ap = x.A;
+        const float* Bp = x.B;
+        int kl = k0, ke = x.kend;
+        if (EXT && g.k_seg > 0) {
+            const int seg = k0 / g.k_seg;
+            const long si = (long)x.bz * (g.K / g.k_seg) + seg;
+            Ap = g.A + g.a_seg_off[si];
+            Bp = g.B + g.b_seg_off[si];
+            kl = k0 - seg * g.k_seg;
+            ke = g.k_seg;
+        }
+        tile_load<BM, A_KC, FAST>(ra, Ap, g.a_i, g.a_k, x.m0, kl, g.M, ke, g.a_vec, 0, 0, tid);
+        tile_load<BN, B_KC, FAST>(rb, Bp, g.b_j, g.b_k, x.n0, kl, g.N, ke, g.b_vec, x.kshift, g.b_kT, tid);
+    };
+    load_tiles(w, w.kbeg);
     for (;;) {
-        const float* A = w.A;
-        const float* B = w.B;
         float* C = w.C;
-        const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend, kshift = w.kshift;
+        const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend;
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int nk = (kend - kbeg + BK - 1) / BK;
-        const bool do_cs = !A_KC && g.colsum != nullptr && w.tn_idx == 0 && tid < BM;
+        const bool do_cs = !EXT && !A_KC && g.colsum != nullptr && w.tn_idx == 0 && tid < BM;
         float cs_acc = 0.f;
         __syncthreads();  // the previous tile's fragment reads are done
         tile_store<BM, A_KC>(sA[0], ra, tid);
@@ -228,10 +249,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         __syncthreads();
 
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) {
-                tile_load<BM, A_KC, FAST>(ra, A, g.a_i, g.a_k, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_vec, 0, 0, tid);
-                tile_load<BN, B_KC, FAST>(rb, B, g.b_j, g.b_k, n0, kbeg + (kt + 1) * BK, g.N, kend, g.b_vec, kshift, g.b_kT, tid);
-            }
+            if (kt + 1 < nk) load_tiles(w, kbeg + (kt + 1) * BK);
             const float* a_s = sA[0];
             const float* b_s = sB[0];
             if (do_cs) {  // image [k][BM]: consecutive threads read consecutive words (zero padded beyond M / kend)
@@ -265,16 +283,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         const int ks = w.ks, xy = w.xy;
         if (more) {
             w = decode(work);
-            tile_load<BM, A_KC, FAST>(ra, w.A, g.a_i, g.a_k, w.m0, w.kbeg, g.M, w.kend, g.a_vec, 0, 0, tid);
-            tile_load<BN, B_KC, FAST>(rb, w.B, g.b_j, g.b_k, w.n0, w.kbeg, g.N, w.kend, g.b_vec, w.kshift, g.b_kT, tid);
+            if (!EXT) load_tiles(w, w.kbeg);   // (EXT: behind the epilogue, whose own operand loads need the registers)
         }
 
         // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const bool whole = m0 + BM <= g.M;  // workgroup-uniform: whole rows, only a per-lane column predicate
         bool final_store = true;
         // 64x64 tiles only: in the larger tiles the summing loop costs the main loop its registers (scratch spills)
-        const bool fix = BM * BN <= 64 * 64 && g.counters != nullptr;
-        if (g.splitk > 1) {
+        const bool fix = !EXT && BM * BN <= 64 * 64 && g.counters != nullptr;
+        if (!EXT && g.splitk > 1) {
             const int ncs = g.colsum ? 1 : 0;
             const long W = g.N + ncs;
             const long slab_k = (long)g.batch * g.M * W;  // one split's slab
@@ -343,7 +360,42 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         if (final_store) {
             if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
             const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
-            if (whole && !g.accumulate) {
+            if (EXT) {   // (the one epilogue of the extended instantiation: bias, ReLU, residual, mask)
+                // residual / ReLU-mask epilogue: the extra operands of four output rows are requested together, then the
+                // four results leave (a lane's accesses are 128-byte-coalesced across the 32 lanes of a column block).
+                // 32-bit element offsets from wave-uniform bases (the host checks the extents): an address is one VGPR
+                const float* res = g.res ? g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch) : nullptr;
+                const float* msk = g.mask ? g.mask + (long)bz * g.mask_batch : nullptr;
+                const unsigned res_ld = (unsigned)g.res_ld, mask_ld = (unsigned)g.mask_ld, ldc = (unsigned)g.ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WN + j * 32 + l31;
+                    const unsigned colc = (unsigned)min(col, g.N - 1);
+                    const float bj = bias ? bias[colc] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            float rv[4], mv[4];
+                            const int row0 = m0 + wm * WM + i * 32 + 4 * lh + 8 * h;   // r = 4 h + q: rows row0 + q
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned row = (unsigned)min(row0 + q, g.M - 1);
+                                rv[q] = res ? res[row * res_ld + colc] : 0.f;
+                                mv[q] = msk ? msk[row * mask_ld + colc] : 1.f;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int row = row0 + q;
+                                float v = acc[i][j][h * 4 + q] + bj + rv[q];
+                                if (g.act == 1) v = as_relu(v);
+                                if (!(mv[q] > 0.f)) v = 0.f;
+                                if (row < g.M && col < g.N) C[(unsigned)row * ldc + (unsigned)col] = v;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise requests all 128 operands first)
+                        }
+                }
+            } else if (whole && !g.accumulate) {
                 float* c0 = C + (long)(m0 + wm * WM + 4 * lh) * g.ldc + n0 + wn * WN + l31;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -387,6 +439,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
             }
         }
         if (!more) break;
+        if (EXT) load_tiles(w, w.kbeg);
     }
 }
 
@@ -634,7 +687,21 @@ int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
         const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);            \
     } while (0)
-    if (fast) {
+    if (k.res || k.mask || k.k_seg > 0) {   // the extended instantiations (as_gemm_f32 has checked a_kc and float4-clean operands)
+#define AS_GEMM_LAUNCH_EXT(BK_)                                                                      \
+    do {                                                                                             \
+        static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, true, BK_, true, true>);    \
+        const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, BK_, true, true>), grid, block, 0, st, k); \
+    } while (0)
+        if constexpr (BM == BN) {   // 128 x 128 and 64 x 64 only
+            if (b_kc) AS_GEMM_LAUNCH_EXT(true);
+            else AS_GEMM_LAUNCH_EXT(false);
+        } else {
+            AS_REQUIRE(false, AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg need a square tile");
+        }
+#undef AS_GEMM_LAUNCH_EXT
+    } else if (fast) {
         if (a_kc && b_kc) AS_GEMM_LAUNCH(true, true, true);
         else if (a_kc && !b_kc) AS_GEMM_LAUNCH(true, false, true);
         else if (!a_kc && b_kc) AS_GEMM_LAUNCH(false, true, true);
@@ -683,8 +750,23 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
     k.bias_off = (const long*)g->bias_off;
+    k.res = g->res; k.res_ld = g->res_ld; k.res_batch = g->res_batch; k.res_off = (const long*)g->res_off;
+    k.mask = g->mask; k.mask_ld = g->mask_ld; k.mask_batch = g->mask_batch;
+    k.k_seg = g->k_seg; k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
+    const bool epi_ops = g->res || g->mask, segmented = g->k_seg > 0;
+    AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && g->precision == 0 && (a_kc || b_kc)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg go with the general kernel only (no colsum, splitk_ws, accumulate, "
+               "split precision or weight-gradient shape)");
+    AS_REQUIRE(!(epi_ops || segmented) || (a_kc && aligned16(g->A) && aligned16(g->B) && a_ld % 4 == 0 && b_ld % 4 == 0 && g->K % 4 == 0 &&
+                                           (b_kc || g->N % 4 == 0) && g->act <= 1),
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg need a reduction-contiguous A, float4-clean operands and act <= 1");
+    AS_REQUIRE(!(epi_ops || segmented) || ((long)g->M * g->ldc < (1L << 31) && (long)g->M * g->res_ld < (1L << 31) &&
+                                           (long)g->M * g->mask_ld < (1L << 31)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg address one batch member's C, res and mask with 32-bit offsets");
+    AS_REQUIRE(!segmented || (g->k_seg % BK == 0 && g->K % g->k_seg == 0 && g->a_seg_off && g->b_seg_off && g->b_kT == 0),
+               AS_ERR_BAD_ARG, "as_gemm_f32: k_seg=%d needs a multiple of %d that divides K=%d and both segment tables", g->k_seg, BK, g->K);
     const bool grouped = g->a_off || g->b_off || g->c_off || g->bias_off;
-    if (grouped) {  // alignment of table offsets is the caller's contract (multiples of 4 floats) -- see header
+    if (grouped || segmented) {  // alignment of table offsets is the caller's contract (multiples of 4 floats) -- see header
         k.a_vec = aligned16(g->A) && a_ld % 4 == 0;
         k.b_vec = aligned16(g->B) && b_ld % 4 == 0;
     }

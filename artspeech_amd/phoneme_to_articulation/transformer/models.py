@@ -13,9 +13,12 @@ dropout 0.1 in training mode) and -- when the reference would take nn.Transforme
 MI355X design: the A*(A+1) channel blocks of a decoder layer run as GROUPED fp32-MFMA GEMMs (``as_gemm_f32`` with
 per-batch offset tables) on block-major tensors, i.e. ~30 launches per layer instead of the reference's ~2 000 small
 kernels; every LayerNorm that feeds a Linear is applied affine-free once per channel and its gamma/beta are folded
-into the consumers' weights; attention probabilities are one masked-softmax kernel between two grouped GEMMs.  The
-building blocks are autograd Functions whose forward and backward both run on the C ABI (``ops.py``); autograd only
-wires them.  Parameters are stored stacked over blocks (one tensor per field and layer).
+into the consumers' weights; the attention core is one fused kernel per group.  Each of the three block groups of a
+layer (self, interaction, cross) is ONE autograd node with a hand-written backward (``ops.ChannelBlocks``): residuals,
+ReLU masks and the per-channel gradient sums ride in GEMM epilogues / segmented reductions instead of separate passes
+over the [blocks, rows, d] activations.  The other building blocks are autograd Functions whose forward and backward
+both run on the C ABI (``ops.py``); autograd only wires them.  Parameters are stored stacked over the blocks of a group
+(one tensor per field, group and layer: a group's gradient is then a whole tensor, not a slice).
 """
 import math
 import os
@@ -27,7 +30,7 @@ import torch.nn.functional as F
 
 from ... import _lib
 from ..encoder_decoder.models import _build_views, _numel, _reference_init
-from .ops import Attention, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize
+from .ops import Attention, ChannelBlocks, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize
 
 FF_DIM = 2048      # nn.TransformerEncoderLayer's default dim_feedforward (not overridden by the reference, :309-313)
 ENC_DROPOUT = 0.1  # ... and its default dropout: the model's `dropout` argument does not reach the encoder
@@ -110,7 +113,8 @@ class ArtSpeechTransformer(nn.Module):
         self.dropout = float(dropout)
         self.head_dims = _lib.Dims(1, A, 1, d, nf // 2, 1)
         self.head_lay = _lib.layout(self.head_dims)
-        NB, K10 = A * (A + 1), (A - 1) * d
+        K10 = (A - 1) * d
+        self._group_sizes = {"proc": A, "inter": A * (A - 1), "input": A}
         P = {}
         # storage only: the values come from _reference_order_state() below (seed-for-seed with the reference)
         _uniform = lambda shape, fan: torch.empty(shape)  # noqa: E731
@@ -126,12 +130,11 @@ class ArtSpeechTransformer(nn.Module):
             for n in ("n1", "n2"):
                 P[e + n + "_w"], P[e + n + "_b"] = torch.ones(d), torch.zeros(d)
         layer0 = {}
-        for name, shape, fan in (("q_w", (NB, d, d), d), ("q_b", (NB, d), d), ("k_w", (NB, d, d), d), ("k_b", (NB, d), d),
-                                 ("v_w", (NB, d, d), d), ("v_b", (NB, d), d), ("o_w", (NB, d, d), d)):
-            layer0[name] = _uniform(shape, fan)
-        layer0["in_w"] = torch.stack([torch.empty(3 * d, d) for _ in range(NB)])
-        layer0["in_b"], layer0["o_b"] = torch.zeros(NB, 3 * d), torch.zeros(NB, d)
-        layer0["ln_w"], layer0["ln_b"] = torch.ones(NB, d), torch.zeros(NB, d)
+        for grp, NB in self._group_sizes.items():
+            for name, shape in (("q_w", (NB, d, d)), ("q_b", (NB, d)), ("k_w", (NB, d, d)), ("k_b", (NB, d)), ("v_w", (NB, d, d)),
+                                ("v_b", (NB, d)), ("o_w", (NB, d, d)), ("o_b", (NB, d)), ("in_w", (NB, 3 * d, d)), ("in_b", (NB, 3 * d)),
+                                ("ln_w", (NB, d)), ("ln_b", (NB, d))):
+                layer0[f"{grp}_{name}"] = torch.empty(shape)
         layer0["il_ln_w"], layer0["il_ln_b"] = torch.ones(A, K10), torch.zeros(A, K10)
         layer0["il_w"], layer0["il_b"] = _uniform((A, d, K10), K10), _uniform((A, d), K10)
         layer0["ff_ln_w"], layer0["ff_ln_b"] = torch.ones(d), torch.zeros(d)
@@ -166,11 +169,11 @@ class ArtSpeechTransformer(nn.Module):
         init["pos_encoding.pe"] = self.pe
         self.load_state_dict(init)
         self._grad_mode_hint = None
-        # block groups of a decoder layer: (slice into the block stacks, tgt channel per block, src channel per block)
+        # block groups of a decoder layer: (tgt channel per block, src channel per block)
         inter_pairs = [(c, i) for c in range(A) for i in range(A) if i != c]
-        self._groups = {"proc": (slice(0, A), tuple(range(A)), tuple(range(A))),
-                        "inter": (slice(A, A * A), tuple(i for _, i in inter_pairs), tuple(c for c, _ in inter_pairs)),
-                        "input": (slice(A * A, NB), tuple(range(A)), (0,) * A)}
+        self._groups = {"proc": (tuple(range(A)), tuple(range(A))),
+                        "inter": (tuple(i for _, i in inter_pairs), tuple(c for c, _ in inter_pairs)),
+                        "input": (tuple(range(A)), (0,) * A)}
 
     # ------------------------------------------------------------------ state_dict contract (the reference's keys)
     def _build_key_map(self):
@@ -187,12 +190,13 @@ class ArtSpeechTransformer(nn.Module):
                               ("norm1.bias", "n1_b"), ("norm2.weight", "n2_w"), ("norm2.bias", "n2_b")):
                 m[e + ref] = (n + mine, None)
             p, n = f"decoder.layers.{l}.", f"dec{l}_"
-            names = ([f"{p}chan_processing_layers.{c}." for c in range(A)]
-                     + [f"{p}chan_interaction_layers.{c}.interactions.{j}." for c in range(A) for j in range(A - 1)]
-                     + [f"{p}chan_input_layers.{c}." for c in range(A)])
-            for b, name in enumerate(names):
-                for ref, mine in _BLOCK:
-                    m[name + ref] = (n + mine, b)
+            names = {"proc": [f"{p}chan_processing_layers.{c}." for c in range(A)],
+                     "inter": [f"{p}chan_interaction_layers.{c}.interactions.{j}." for c in range(A) for j in range(A - 1)],
+                     "input": [f"{p}chan_input_layers.{c}." for c in range(A)]}
+            for grp, blocks in names.items():
+                for b, name in enumerate(blocks):
+                    for ref, mine in _BLOCK:
+                        m[name + ref] = (f"{n}{grp}_{mine}", b)
             for c in range(A):
                 q = f"{p}chan_interaction_layers.{c}.linear."
                 m[q + "0.weight"], m[q + "0.bias"] = (n + "il_ln_w", c), (n + "il_ln_b", c)
@@ -302,41 +306,37 @@ class ArtSpeechTransformer(nn.Module):
         :47-60 and the in_proj of :62-67): depends on the encoder output only, so generate() computes it once per layer
         instead of once per generated frame."""
         P, d = self.P, self.embed_dim
-        sl, _, src_idx = self._groups["input"]
-        n = f"dec{l}_"
-        ident = tuple(range(sl.stop - sl.start))
-        ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
-        wk, bk = self._fold(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
-        wv, bv = self._fold(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
+        _, src_idx = self._groups["input"]
+        n = f"dec{l}_input_"
+        ident = tuple(range(self._group_sizes["input"]))
+        ln_w, ln_b = P[n + "ln_w"], P[n + "ln_b"]
+        wk, bk = self._fold(P[n + "k_w"], ln_w, ln_b, P[n + "k_b"])
+        wv, bv = self._fold(P[n + "v_w"], ln_w, ln_b, P[n + "v_b"])
         k = GroupedLinear.apply(mem_hat, wk, bk, src_idx, True)
         v = GroupedLinear.apply(mem_hat, wv, bv, src_idx, True)
-        in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
+        in_w, in_b = P[n + "in_w"], P[n + "in_b"]
         return (GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False),
                 GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False))
 
-    def _blocks(self, l, group, xhat_tgt, xhat_src, attn_mask, kpm, B, kv=None):
-        """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> [G, R, d]."""
+    def _blocks(self, l, group, xhat_tgt, xhat_src, attn_mask, kpm, B, kv=None, cat=None):
+        """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> [G, R, d], or with
+        cat = (A, per) the concatenation over the `per` blocks of each channel, [A, R, per * d] (:133-162)."""
         P, d = self.P, self.embed_dim
-        sl, tgt_idx, src_idx = self._groups[group]
-        n = f"dec{l}_"
-        G = sl.stop - sl.start
-        ident = tuple(range(G))
-        ln_w, ln_b = P[n + "ln_w"][sl], P[n + "ln_b"][sl]
-        wq, bq = self._fold(P[n + "q_w"][sl], ln_w, ln_b, P[n + "q_b"][sl])
+        tgt_idx, src_idx = self._groups[group]
+        n = f"dec{l}_{group}_"
+        if kv is None:
+            return ChannelBlocks.apply(xhat_tgt, xhat_src, P[n + "q_w"], P[n + "q_b"], P[n + "k_w"], P[n + "k_b"], P[n + "v_w"],
+                                       P[n + "v_b"], P[n + "in_w"], P[n + "in_b"], P[n + "o_w"], P[n + "o_b"], P[n + "ln_w"],
+                                       P[n + "ln_b"], attn_mask, kpm, (tgt_idx, src_idx, B, self.num_heads, cat))
+        # generate(): the memory side (k2, v2) was projected once per call (_memory_kv); inference only
+        assert cat is None and not torch.is_grad_enabled()
+        ident = tuple(range(self._group_sizes[group]))
+        wq, bq = self._fold(P[n + "q_w"], P[n + "ln_w"], P[n + "ln_b"], P[n + "q_b"])
         q = GroupedLinear.apply(xhat_tgt, wq, bq, tgt_idx, True)
-        in_w, in_b = P[n + "in_w"][sl], P[n + "in_b"][sl]
+        in_w, in_b = P[n + "in_w"], P[n + "in_b"]
         q2 = GroupedLinear.apply(q, in_w[:, :d], in_b[:, :d], ident, False)
-        if kv is not None:
-            k2, v2 = kv
-        else:
-            wk, bk = self._fold(P[n + "k_w"][sl], ln_w, ln_b, P[n + "k_b"][sl])
-            wv, bv = self._fold(P[n + "v_w"][sl], ln_w, ln_b, P[n + "v_b"][sl])
-            k = GroupedLinear.apply(xhat_src, wk, bk, src_idx, True)
-            v = GroupedLinear.apply(xhat_src, wv, bv, src_idx, True)
-            k2 = GroupedLinear.apply(k, in_w[:, d:2 * d], in_b[:, d:2 * d], ident, False)
-            v2 = GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False)
-        ctx = Attention.apply(q2, k2, v2, attn_mask, kpm, B, self.num_heads)
-        o = GroupedLinear.apply(ctx, P[n + "o_w"][sl], P[n + "o_b"][sl], ident, False)
+        ctx = Attention.apply(q2, kv[0], kv[1], attn_mask, kpm, B, self.num_heads)
+        o = GroupedLinear.apply(ctx, P[n + "o_w"], P[n + "o_b"], ident, False)
         return q + o  # the residual is the PROJECTED query (:98)
 
     def _decoder_layer(self, l, x, mem_hat, tgt_mask, memory_mask, tgt_kpm, mem_kpm, B, mem_kv=None, last_only=False):
@@ -355,8 +355,7 @@ class ArtSpeechTransformer(nn.Module):
             R = B
         else:
             phat_q = phat
-        inter_blocks = self._blocks(l, "inter", phat_q, phat, tgt_mask, tgt_kpm, B)          # [A*(A-1), R, d]
-        cat = inter_blocks.view(A, A - 1, R, d).permute(0, 2, 1, 3).reshape(A, R, (A - 1) * d)  # concat over the other channels
+        cat = self._blocks(l, "inter", phat_q, phat, tgt_mask, tgt_kpm, B, cat=(A, A - 1))   # [A, R, (A-1) d]: concat over the others
         wl, bl = self._fold(P[n + "il_w"], P[n + "il_ln_w"], P[n + "il_ln_b"], P[n + "il_b"])
         inter = GroupedLinear.apply(Normalize.apply(cat), wl, bl, tuple(range(A)), True)      # [A, R, d]
         inp = self._blocks(l, "input", Normalize.apply(inter), mem_hat, memory_mask, mem_kpm, B, kv=mem_kv)

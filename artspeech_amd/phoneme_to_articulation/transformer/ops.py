@@ -44,6 +44,13 @@ def _table(dev, key, build):
     return _TABLES[k]
 
 
+def _table32(dev, key, build):
+    k = (dev, key)
+    if k not in _TABLES:
+        _TABLES[k] = torch.tensor(build(), dtype=torch.int32, device=dev)
+    return _TABLES[k]
+
+
 def _slab(dev):
     if dev not in _SLAB:
         _SLAB[dev] = torch.empty(8 << 20, dtype=torch.float32, device=dev)  # split-K partial tiles (32 MB)
@@ -217,108 +224,279 @@ def _key_major_mask(attn_mask, Tk, T):
     return mt
 
 
-class Attention(torch.autograd.Function):
+def _z_tables(dev, G, B, T, Tk, d, heads):
+    R, Rk, dh, Z = B * T, B * Tk, d // heads, G * B * heads
+    zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
+    zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
+    zs = _table(dev, ("zs", Z, T, Tk), lambda: [z * T * Tk for z in range(Z)])
+    return zq, zk, zs
+
+
+def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
     """Multi-head attention core on projected tensors (nn.MultiheadAttention semantics, float additive masks):
-    Q [G, B*T, d], K/V [G, B*Tk, d] -> ctx [G, B*T, d];  P = softmax(Q_h K_h^T / sqrt(dh) + attn_mask[b] + kpm[b])."""
-
-    @staticmethod
-    def forward(ctx, Q, K, V, attn_mask, kpm, B, heads):
-        Q, K, V = _c(Q), _c(K), _c(V)
-        G, R, d = Q.shape
-        Rk = K.shape[1]
-        T, Tk, dh = R // B, Rk // B, d // heads
-        Z = G * B * heads
-        dev = Q.device
-        L = _lib.lib()
-        scale = 1.0 / math.sqrt(dh)
-        if FUSED_ATTENTION and L.as_attention_supported(T, Tk, d, heads):
-            # scores stay in registers (as_attention_fwd); training additionally keeps the probabilities, key-major
-            training = any(ctx.needs_input_grad[:3])
-            out = torch.empty_like(Q)
-            Pt = torch.empty((Z, Tk, T), dtype=torch.float32, device=dev) if training else None
-            mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
-            km = _c(kpm) if kpm is not None else None
-            _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
-                                          _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
-            if training:
-                ctx.save_for_backward(Q, K, V, Pt, out)
-                ctx.meta = (B, heads, scale, None, None, None)
-            return out
-        zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
-        zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
-        zs = _table(dev, ("zs", Z, T, Tk), lambda: [z * T * Tk for z in range(Z)])
-        P = torch.empty((Z, T, Tk), dtype=torch.float32, device=dev)
-        _gemm(A=Q, B=K, C=P, M=T, N=Tk, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tk, batch=Z, a_off=zq, b_off=zk, c_off=zs)
-        scale = 1.0 / math.sqrt(dh)
-        am = _c(attn_mask) if attn_mask is not None else None
-        km = _c(kpm) if kpm is not None else None
-        _lib.check(_lib.lib().as_attn_softmax(_lib.ptr(P), Z, T, Tk, heads, B, scale, _lib.ptr(am), _lib.ptr(km), _lib.stream_ptr()),
-                   "as_attn_softmax")
-        out = torch.empty_like(Q)
-        _gemm(A=P, B=V, C=out, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
-        ctx.save_for_backward(Q, K, V, P)
-        ctx.meta = (B, heads, scale, zq, zk, zs)
-        return out
-
-    @staticmethod
-    def backward(ctx, dctx):
-        saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
-        if len(saved) == 5:
-            return Attention._backward_key_major(ctx, dctx, saved)
-        Q, K, V, P = saved
-        B, heads, scale, zq, zk, zs = ctx.meta
-        G, R, d = Q.shape
-        Rk = K.shape[1]
-        T, Tk, dh = R // B, Rk // B, d // heads
-        Z = G * B * heads
-        dctx = _c(dctx)
-        dP = torch.empty_like(P)
-        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-        # dP = dctx V^T ; dV = P^T dctx
-        _gemm(A=dctx, B=V, C=dP, M=T, N=Tk, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tk, batch=Z, a_off=zq, b_off=zk, c_off=zs)
-        _gemm(A=P, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=1, a_k=Tk, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
-        _lib.check(_lib.lib().as_attn_softmax_bwd(_lib.ptr(P), _lib.ptr(dP), Z, T, Tk, scale, _lib.stream_ptr()), "as_attn_softmax_bwd")
-        # dQ = dS K ; dK = dS^T Q
-        _gemm(A=dP, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
-        _gemm(A=dP, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=1, a_k=Tk, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
-        return dQ, dK, dV, None, None, None, None
-
-
-def _attention_backward_key_major(ctx, dctx, saved):
-    """Backward of the fused forward: the same five products as the unfused path, on the KEY-major probabilities
-    P^T [Z][Tk][T] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
-    second pass over the scores."""
-    Q, K, V, Pt, out = saved
-    B, heads, scale = ctx.meta[:3]
+    Q [G, B*T, d], K/V [G, B*Tk, d] -> ctx [G, B*T, d];  P = softmax(Q_h K_h^T / sqrt(dh) + attn_mask[b] + kpm[b]).
+    Returns (ctx, tensors to keep for attention_backward or None, scale)."""
     G, R, d = Q.shape
     Rk = K.shape[1]
     T, Tk, dh = R // B, Rk // B, d // heads
     Z = G * B * heads
     dev = Q.device
-    zq = _table(dev, ("zq", G, B, T, d, heads), lambda: [g * R * d + b * T * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
-    zk = _table(dev, ("zq", G, B, Tk, d, heads), lambda: [g * Rk * d + b * Tk * d + h * dh for g in range(G) for b in range(B) for h in range(heads)])
-    zs = _table(dev, ("zs", Z, T, Tk), lambda: [z * T * Tk for z in range(Z)])
+    L = _lib.lib()
+    scale = 1.0 / math.sqrt(dh)
+    km = _c(kpm) if kpm is not None else None
+    if FUSED_ATTENTION and L.as_attention_supported(T, Tk, d, heads):
+        # scores stay in registers (as_attention_fwd); training additionally keeps the probabilities, key-major
+        out = torch.empty_like(Q)
+        Pt = torch.empty((Z, Tk, T), dtype=torch.float32, device=dev) if training else None
+        mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
+        _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
+                                      _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
+        return out, ((Q, K, V, Pt, out) if training else None), scale
+    zq, zk, zs = _z_tables(dev, G, B, T, Tk, d, heads)
+    P = torch.empty((Z, T, Tk), dtype=torch.float32, device=dev)
+    _gemm(A=Q, B=K, C=P, M=T, N=Tk, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tk, batch=Z, a_off=zq, b_off=zk, c_off=zs)
+    am = _c(attn_mask) if attn_mask is not None else None
+    _lib.check(L.as_attn_softmax(_lib.ptr(P), Z, T, Tk, heads, B, scale, _lib.ptr(am), _lib.ptr(km), _lib.stream_ptr()), "as_attn_softmax")
+    out = torch.empty_like(Q)
+    _gemm(A=P, B=V, C=out, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
+    return out, ((Q, K, V, P) if training else None), scale
+
+
+def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None):
+    """(dQ, dK, dV) of attention_forward; the three may be handed in (contiguous slices of a caller's buffer)."""
+    Q, K, V = saved[:3]
+    G, R, d = Q.shape
+    Rk = K.shape[1]
+    T, Tk, dh = R // B, Rk // B, d // heads
+    Z = G * B * heads
+    dev = Q.device
+    zq, zk, zs = _z_tables(dev, G, B, T, Tk, d, heads)
     dctx = _c(dctx)
-    dPt = torch.empty_like(Pt)
-    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-    # dV = P^T dctx
-    _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
-    if FUSED_DS:
-        # dS^T = P^T o (V dctx^T - D) * scale in one kernel: dP is never formed
-        _lib.check(_lib.lib().as_attention_bwd_ds(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T,
-                                                  Tk, d, scale, _lib.stream_ptr()), "as_attention_bwd_ds")
-    else:
-        _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
-        dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B,
-                                                    heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
-    # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
-    _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
-    _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
-    return dQ, dK, dV, None, None, None, None
+    dQ = torch.empty_like(Q) if dQ is None else dQ
+    dK = torch.empty_like(K) if dK is None else dK
+    dV = torch.empty_like(V) if dV is None else dV
+    if len(saved) == 5:
+        # backward of the fused forward: the same five products as the unfused path, on the KEY-major probabilities
+        # P^T [Z][Tk][T] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
+        # second pass over the scores
+        Pt, out = saved[3:]
+        dPt = torch.empty_like(Pt)
+        # dV = P^T dctx
+        _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+        if FUSED_DS:
+            # dS^T = P^T o (V dctx^T - D) * scale in one kernel: dP is never formed
+            _lib.check(_lib.lib().as_attention_bwd_ds(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T,
+                                                      Tk, d, scale, _lib.stream_ptr()), "as_attention_bwd_ds")
+        else:
+            _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
+            dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B,
+                                                        heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
+        # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
+        _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
+        _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+        return dQ, dK, dV
+    P = saved[3]
+    dP = torch.empty_like(P)
+    # dP = dctx V^T ; dV = P^T dctx
+    _gemm(A=dctx, B=V, C=dP, M=T, N=Tk, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tk, batch=Z, a_off=zq, b_off=zk, c_off=zs)
+    _gemm(A=P, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=1, a_k=Tk, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+    _lib.check(_lib.lib().as_attn_softmax_bwd(_lib.ptr(P), _lib.ptr(dP), Z, T, Tk, scale, _lib.stream_ptr()), "as_attn_softmax_bwd")
+    # dQ = dS K ; dK = dS^T Q
+    _gemm(A=dP, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
+    _gemm(A=dP, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=1, a_k=Tk, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+    return dQ, dK, dV
 
 
-Attention._backward_key_major = staticmethod(_attention_backward_key_major)
+class Attention(torch.autograd.Function):
+    """attention_forward / attention_backward as an autograd node (the encoder layers; the decoder's blocks go through
+    ChannelBlocks)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, attn_mask, kpm, B, heads):
+        out, saved, scale = attention_forward(_c(Q), _c(K), _c(V), attn_mask, kpm, B, heads, any(ctx.needs_input_grad[:3]))
+        if saved is not None:
+            ctx.save_for_backward(*saved)
+        ctx.meta = (B, heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
+        return (*attention_backward(saved, *ctx.meta, dctx), None, None, None, None)
+
+
+def _ptr(t, off_floats=0):
+    return t.data_ptr() + 4 * off_floats
+
+
+class ChannelBlocks(torch.autograd.Function):
+    """One GROUP of ChannelProcessingLayers (reference transformer/models.py:37-100; the A self blocks, the A*(A-1)
+    interaction blocks or the A cross-attention blocks of a decoder layer, :165-277) as ONE autograd node with a
+    hand-written backward:
+
+        q = relu(LN(x_tgt) Wq^T + bq), k / v likewise from x_src      (the LayerNorm is shared: :70-76; its affine is folded
+        q2, k2, v2 = in_proj(q, k, v); ctx = attention(q2, k2, v2)      into the three weights, x_* arrive normalised)
+        out = q + ctx Wo^T + bo                                        (the residual is the PROJECTED query, :98)
+
+    xt [Ct, R, d] / xs [Cs, Rs, d] are channel-major, block g reads channels tgt[g] / src[g].  cat = (A, per): the output
+    is written as [A, R, per * d] -- block g = c * per + j lands in columns [j*d, (j+1)*d) of channel c, which is the
+    concatenation over the other channels that ChannelInteractionsLayer builds (:133-162) -- else block-major [G, R, d].
+
+    What the fusion buys over one autograd node per Linear (measured): the residual is added by the
+    out-projection GEMM's epilogue; in the backward the ReLU masks and the residual's gradient are applied by the
+    epilogue of the in-projection's input-gradient GEMM (no pass over the [G, R, d] activations in between), the k and v
+    sides run as one batch of 2G, the in-projection reads and writes the stacked [G, 3d, d] weight / gradient in place, and
+    the per-channel input gradients are sums over the blocks of a channel INSIDE one segmented GEMM (as_gemm.k_seg)."""
+
+    @staticmethod
+    def forward(ctx, xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm, cfg):
+        tgt, src, B, heads, cat = cfg
+        xt, xs = _c(xt), _c(xs)
+        q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b = (_c(p) for p in (q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w,
+                                                                                            o_b, ln_w, ln_b))
+        G, d = q_w.shape[0], q_w.shape[-1]
+        (Ct, R, _), (Cs, Rs, _) = xt.shape, xs.shape
+        dev = xt.device
+        L, st = _lib.lib(), _lib.stream_ptr()
+        training = any(ctx.needs_input_grad)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        # LayerNorm affine folded into the three pre-projections
+        W3, b3 = new(3, G, d, d), new(3, G, d)
+        for j, (w, b) in enumerate(((q_w, q_b), (k_w, k_b), (v_w, v_b))):
+            _lib.check(L.as_fold_ln(_lib.ptr(w), _lib.ptr(ln_w), _lib.ptr(ln_b), _lib.ptr(b), _ptr(W3, j * G * d * d), _ptr(b3, j * G * d), G,
+                                    d, d, st), "as_fold_ln")
+        same = R == Rs
+        pre = new(3, G, R, d) if same else None          # q, k, v (after the ReLU), one buffer when the row counts agree
+        q = pre[0] if same else new(G, R, d)
+        kv = pre[1:] if same else new(2, G, Rs, d)
+        t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])
+        s_off2 = _table(dev, ("src2", src, Rs * d), lambda: [s * Rs * d for s in src] * 2)
+        _gemm(A=xt, B=W3, C=q, bias=b3, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_off=t_off, b_batch=d * d,
+              c_batch=R * d, bias_batch=d, act=1)
+        _gemm(A=xs, B=_ptr(W3, G * d * d), C=kv, bias=_ptr(b3, G * d), M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G,
+              a_off=s_off2, b_batch=d * d, c_batch=Rs * d, bias_batch=d, act=1)
+        # MHA in-projection: slice j of the stacked [G, 3d, d] weight, read in place
+        w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
+        bi_off = _table(dev, ("inb", G, d), lambda: [g * 3 * d + j * d for j in range(3) for g in range(G)])
+        p2 = new(3, G, R, d) if same else None
+        q2 = p2[0] if same else new(G, R, d)
+        kv2 = p2[1:] if same else new(2, G, Rs, d)
+        if same:
+            _gemm(A=pre, B=in_w, C=p2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=3 * G, a_batch=R * d,
+                  b_off=w_off, c_batch=R * d, bias_off=bi_off)
+        else:
+            _gemm(A=q, B=in_w, C=q2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d,
+                  b_batch=3 * d * d, c_batch=R * d, bias_batch=3 * d)
+            _gemm(A=kv, B=in_w, C=kv2, bias=in_b, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G, a_batch=Rs * d,
+                  b_off=w_off[G:], c_batch=Rs * d, bias_off=bi_off[G:])
+        att, att_saved, scale = attention_forward(q2, kv2[0], kv2[1], attn_mask, kpm, B, heads, training)
+        # out = q + out_proj(ctx): the residual goes in with the GEMM's epilogue, the result straight into its final layout
+        if cat is not None:
+            A_, per = cat
+            assert A_ * per == G
+            out = new(A_, R, per * d)
+            ldo = per * d
+            c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
+            lay = dict(c_off=c_off)
+        else:
+            out = new(G, R, d)
+            ldo, c_off = d, None
+            lay = dict(c_batch=R * d)
+        _gemm(A=att, B=o_w, C=out, bias=o_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=ldo, batch=G, a_batch=R * d, b_batch=d * d,
+              bias_batch=d, res=q, res_ld=d, res_batch=R * d, precision=0, **lay)
+        if training:
+            ctx.save_for_backward(xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, *att_saved)
+            ctx.meta = (tgt, src, B, heads, cat, scale, ldo)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
+        xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att = saved[:13]
+        att_saved = saved[13:]
+        tgt, src, B, heads, cat, scale, ldo = ctx.meta
+        G, d = q_w.shape[0], q_w.shape[-1]
+        (Ct, R, _), (Cs, Rs, _) = xt.shape, xs.shape
+        dev = xt.device
+        L, st = _lib.lib(), _lib.stream_ptr()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        slab = _slab(dev)
+        ws = dict(splitk_ws=slab, splitk_ws_floats=slab.numel())
+        dout = _c(dout)
+        if cat is not None:
+            A_, per = cat
+            c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
+            a_lay, r_lay = dict(a_off=c_off), dict(res_off=c_off)
+        else:
+            a_lay, r_lay = dict(a_batch=R * d), dict(res_batch=R * d)
+        same = R == Rs
+        # ---- out-projection: d ctx = dout Wo ; dWo = dout^T ctx (+ its bias gradient as the column sums of dout)
+        datt = new(G, R, d)
+        _gemm(A=dout, B=o_w, C=datt, M=R, N=d, K=d, a_i=ldo, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, b_batch=d * d, c_batch=R * d, **a_lay)
+        do_w, do_b = new(G, d, d), new(G, d)
+        _gemm(A=dout, B=att, C=do_w, M=d, N=d, K=R, a_i=1, a_k=ldo, b_j=1, b_k=d, ldc=d, batch=G, b_batch=R * d, c_batch=d * d,
+              colsum=do_b, colsum_batch=d, **a_lay, **ws)
+        # ---- attention core
+        dp2 = new(3, G, R, d) if same else None
+        dq2 = dp2[0] if same else new(G, R, d)
+        dkv2 = dp2[1:] if same else new(2, G, Rs, d)
+        attention_backward(att_saved, B, heads, scale, datt, dQ=dq2, dK=dkv2[0], dV=dkv2[1])
+        del datt
+        # ---- in-projection: weight gradients into the stacked [G, 3d, d] tensor; input gradients through the ReLU masks of
+        # q / k / v, the query's together with the gradient that arrives over the residual (`dout` itself)
+        din_w, din_b = new(G, 3 * d, d), new(G, 3 * d)
+        for j, (dz, y, rows) in enumerate(((dq2, q, R), (dkv2[0], kv[0], Rs), (dkv2[1], kv[1], Rs))):
+            _gemm(A=dz, B=y, C=_ptr(din_w, j * d * d), M=d, N=d, K=rows, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=G, a_batch=rows * d,
+                  b_batch=rows * d, c_batch=3 * d * d, colsum=_ptr(din_b, j * d), colsum_batch=3 * d, **ws)
+        dq, dkv = new(G, R, d), new(2, G, Rs, d)
+        w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
+        _gemm(A=dq2, B=in_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=3 * d * d,
+              c_batch=R * d, res=dout, res_ld=ldo, mask=q, mask_ld=d, mask_batch=R * d, precision=0, **r_lay)
+        _gemm(A=dkv2, B=in_w, C=dkv, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d, b_off=w_off[G:],
+              c_batch=Rs * d, mask=kv, mask_ld=d, mask_batch=Rs * d, precision=0)
+        del dp2, dq2, dkv2
+        # ---- pre-projections: gradients of the folded weights, unfolded onto (W, gamma, beta)
+        t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])
+        s_off2 = _table(dev, ("src2", src, Rs * d), lambda: [s * Rs * d for s in src] * 2)
+        dWf, dbf = new(3, G, d, d), new(3, G, d)
+        _gemm(A=dq, B=xt, C=dWf, M=d, N=d, K=R, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_off=t_off, c_batch=d * d,
+              colsum=dbf, colsum_batch=d, **ws)
+        _gemm(A=dkv, B=xs, C=_ptr(dWf, G * d * d), M=d, N=d, K=Rs, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d,
+              b_off=s_off2, c_batch=d * d, colsum=_ptr(dbf, G * d), colsum_batch=d, **ws)
+        dW3, dg3, db3 = new(3, G, d, d), new(3, G, d), new(3, G, d)
+        for j, w in enumerate((q_w, k_w, v_w)):
+            _lib.check(L.as_unfold_ln(_ptr(dWf, j * G * d * d), _ptr(dbf, j * G * d), _lib.ptr(w), _lib.ptr(ln_w), _lib.ptr(ln_b),
+                                      _ptr(dW3, j * G * d * d), _ptr(dg3, j * G * d), _ptr(db3, j * G * d), G, d, d, st), "as_unfold_ln")
+        dln_w, dln_b = dg3.sum(0), db3.sum(0)   # the three projections share the block's LayerNorm
+        # ---- input gradients per channel: sums over the blocks that read the channel
+        dxt = _channel_sums(dq.view(G, R, d), W3[0], tgt, Ct, R, d) if ctx.needs_input_grad[0] else None
+        dxs = _channel_sums(dkv.view(2 * G, Rs, d), W3[1:].reshape(2 * G, d, d), tuple(src) * 2, Cs, Rs, d) if ctx.needs_input_grad[1] else None
+        return (dxt, dxs, dW3[0], dbf[0], dW3[1], dbf[1], dW3[2], dbf[2], din_w, din_b, do_w, do_b, dln_w, dln_b, None, None, None)
+
+
+def _channel_sums(dz, W, idx, Cn, R, d):
+    """dx[c] = sum over the blocks g with idx[g] == c of dz[g] W[g]  (dz [N, R, d], W [N, d, d], dx [Cn, R, d])."""
+    N = len(idx)
+    dev = dz.device
+    dx = torch.empty((Cn, R, d), dtype=torch.float32, device=dev)
+    if N == Cn and tuple(idx) == tuple(range(N)):
+        _gemm(A=dz, B=W, C=dx, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d)
+        return dx
+    blocks = [[g for g in range(N) if idx[g] == c] for c in range(Cn)]
+    per = len(blocks[0])
+    if per > 0 and all(len(b) == per for b in blocks) and d % 32 == 0 and d % 4 == 0:
+        # one GEMM per channel over the concatenated reduction (per * d), segment s = block blocks[c][s]
+        a_seg = _table(dev, ("aseg", tuple(idx), Cn, R * d), lambda: [g * R * d for b in blocks for g in b])
+        b_seg = _table(dev, ("bseg", tuple(idx), Cn, d * d), lambda: [g * d * d for b in blocks for g in b])
+        _gemm(A=dz, B=W, C=dx, M=R, N=d, K=per * d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=Cn, c_batch=R * d, k_seg=d, a_seg_off=a_seg,
+              b_seg_off=b_seg, precision=0)
+        return dx
+    part = torch.empty((N, R, d), dtype=torch.float32, device=dev)
+    _gemm(A=dz, B=W, C=part, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d)
+    srct = _table32(dev, ("idx32", tuple(idx)), lambda: list(idx))
+    _lib.check(_lib.lib().as_group_reduce(_lib.ptr(part), _lib.ptr(srct), N, Cn, R * d, _lib.ptr(dx), _lib.stream_ptr()), "as_group_reduce")
+    return dx
 
 
 class Heads(torch.autograd.Function):

@@ -214,6 +214,22 @@ typedef struct as_gemm {
        have (0 = the whole chip), e.g. 192 while a 64-workgroup recurrence kernel runs beside it on another stream; only the
        split-K factor depends on it, never the result's summation order for a given factor. */
     int32_t cu_budget;
+    /* optional epilogue operands of the general kernel (forward / input-gradient shapes; refused together with colsum,
+       splitk_ws-driven split-K and the weight-gradient kernel):  C = mask > 0 ? act(acc + bias + res) : 0.
+       res  [.][M][N] through (res_ld, res_batch | res_off): a residual added before the activation -- the `q + out_proj(ctx)`
+            of a ChannelProcessingLayer (transformer/models.py:98) written by the out-projection GEMM itself, or in the
+            backward the gradient arriving over that residual, added to the in-projection's input gradient;
+       mask [.][M][N] through (mask_ld, mask_batch): the saved OUTPUT of a ReLU whose backward this GEMM's result goes
+            through (dz = dy * [y > 0], models.py:47-60 through autograd) -- no separate pass over the activations. */
+    const float* res; int64_t res_ld, res_batch; const int64_t* res_off;
+    const float* mask; int64_t mask_ld, mask_batch;
+    /* optional SEGMENTED reduction (a_k == 1 input-gradient / forward shapes of the general kernel): the reduction index is
+       cut into K / k_seg segments of k_seg (a multiple of 32) and segment s of batch member g reads its A rows from
+       A + a_seg_off[g * nseg + s] and its B panel from B + b_seg_off[g * nseg + s] (element offsets, multiples of 4; the
+       batch strides / offset tables of A and B are then ignored; inside a segment the ordinary strides apply with k counted
+       from the segment's start).  Sums the input gradients of all blocks that read one source channel in ONE GEMM
+       (dx[c] = sum_g dz[g] W[g] over the blocks g with src[g] = c) instead of per-block partial tensors + a reduce pass. */
+    int32_t k_seg; const int64_t* a_seg_off; const int64_t* b_seg_off;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 

@@ -176,6 +176,73 @@ def test_gemm_batched_strided_and_shift(dev):
                      rtol=2e-5, atol=1e-4, what=f"batched shift, direction {d}")
 
 
+@pytest.mark.parametrize("R,d,G,big", [(200, 64, 6, False), (1500, 256, 12, False), (77, 32, 3, False), (6400, 256, 6, True)])
+def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
+    """as_gemm.res / .mask / .k_seg (the fused pieces of a ChannelProcessingLayer group, transformer/models.py:70-100 and its
+    autograd): out-projection + residual written into the concatenated layout; in-projection input gradient + residual
+    gradient through the ReLU mask; per-channel input gradients summed over the blocks of a channel by ONE segmented GEMM."""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(R + d + G)
+    A_ = 3 if G % 3 == 0 else 1
+    per = G // A_
+    ctx = rng.randn(G, R, d).astype(np.float32)
+    w = (rng.randn(G, d, d) / np.sqrt(d)).astype(np.float32)
+    b = rng.randn(G, d).astype(np.float32)
+    q = np.maximum(rng.randn(G, R, d), 0).astype(np.float32)
+    tbl = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)  # noqa: E731
+
+    def call(**kw):
+        g = _lib.Gemm()
+        g.batch = 1
+        for k, v in kw.items():
+            setattr(g, k, v.data_ptr() if torch.is_tensor(v) else v)
+        _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+        torch.cuda.synchronize()
+
+    # (1) out[c, :, j*d:(j+1)*d] = q[g] + ctx[g] w[g]^T + b[g], g = c * per + j: concatenated layout through c_off / ldc
+    t_ctx, t_w, t_b, t_q = T_(ctx, dev), T_(w, dev), T_(b, dev), T_(q, dev)
+    out = torch.full((A_, R, per * d), float("nan"), device=dev)
+    coff = tbl([c * R * per * d + j * d for c in range(A_) for j in range(per)])
+    call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
+         bias_batch=d, c_off=coff, res=t_q, res_ld=d, res_batch=R * d)
+    ref = q + np.einsum("grk,gnk->grn", ctx.astype(np.float64), w) + b[:, None]
+    ref_cat = ref.reshape(A_, per, R, d).transpose(0, 2, 1, 3).reshape(A_, R, per * d)
+    assert_close(out.cpu().numpy(), ref_cat, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="out-projection + residual, concatenated")
+
+    # (2) dq[g] = (dq2[g] w[g] + dout_cat[block g]) * [q[g] > 0]: NN product, residual read through the table, ReLU mask
+    dq2 = rng.randn(G, R, d).astype(np.float32)
+    dcat = rng.randn(A_, R, per * d).astype(np.float32)
+    t_dq2, t_dcat = T_(dq2, dev), T_(dcat, dev)
+    dq = torch.full((G, R, d), float("nan"), device=dev)
+    call(A=t_dq2, B=t_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=d * d, c_batch=R * d,
+         res=t_dcat, res_ld=per * d, res_off=coff, mask=t_q, mask_ld=d, mask_batch=R * d)
+    dres = dcat.reshape(A_, R, per, d).transpose(0, 2, 1, 3).reshape(G, R, d)
+    ref = (np.einsum("grn,gnk->grk", dq2.astype(np.float64), w) + dres) * (q > 0)
+    assert_close(dq.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="input gradient + residual gradient, masked")
+    assert (dq.cpu().numpy()[q <= 0] == 0).all()
+
+    # (3) dx[c] = sum over the blocks g with src[g] = c of dz[g] w[g]: one GEMM with K = per * d in segments of d
+    if d % 32 == 0:
+        src = [(g * 7 + 1) % A_ for g in range(G)] if A_ > 1 else [0] * G
+        src = sorted(src)                                     # any grouping; here `per` blocks per channel
+        if all(src.count(c) == per for c in range(A_)):
+            blocks = [[g for g in range(G) if src[g] == c] for c in range(A_)]
+            aseg = tbl([g * R * d for c in range(A_) for g in blocks[c]])
+            bseg = tbl([g * d * d for c in range(A_) for g in blocks[c]])
+            dx = torch.full((A_, R, d), float("nan"), device=dev)
+            call(A=t_dq2, B=t_w, C=dx, M=R, N=d, K=per * d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=A_, c_batch=R * d, k_seg=d,
+                 a_seg_off=aseg, b_seg_off=bseg)
+            ref = np.stack([sum(dq2[g].astype(np.float64) @ w[g] for g in blocks[c]) for c in range(A_)])
+            assert_close(dx.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(per * d), what="segmented reduction")
+    # contract: the extended operands are refused where the kernel that would run does not know them
+    g = _lib.Gemm()
+    g.A, g.B, g.C, g.res = t_dq2.data_ptr(), t_w.data_ptr(), dq.data_ptr(), t_dcat.data_ptr()
+    g.M, g.N, g.K, g.batch = d, d, R, 1
+    g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = 1, d, 1, d, d   # weight-gradient shape
+    assert L.as_gemm_f32(C.byref(g), _lib.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(384, 128, 6400, 2), (256, 256, 4096, 3), (45, 64, 768, 1), (6400, 256, 768, 1), (100, 256, 2048, 5)])
 def test_gemm_split_k_paths(dev, M, N, K, batch):
     """Long reductions under few output tiles take the split-K paths: slabs summed by the last workgroup to arrive at a tile

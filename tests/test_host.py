@@ -366,8 +366,9 @@ def test_ctypes_structs_match_the_header_layout():
 #include <stdio.h>
 #include "artspeech_hip.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(as_opts), offsetof(as_opts, dout_presigmoid), sizeof(as_gemm), offsetof(as_gemm, precision),
-           offsetof(as_gemm, b_kshift_batch), sizeof(as_dims), offsetof(as_gemm, cu_budget));
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(as_opts), offsetof(as_opts, dout_presigmoid), sizeof(as_gemm), offsetof(as_gemm, precision),
+           offsetof(as_gemm, b_kshift_batch), sizeof(as_dims), offsetof(as_gemm, cu_budget), offsetof(as_gemm, res_off),
+           offsetof(as_gemm, mask_batch), offsetof(as_gemm, b_seg_off));
     return 0;
 }
 """
@@ -379,7 +380,8 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", inc, c, "-o", exe])
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     want = [C.sizeof(_lib.Opts), _lib.Opts.dout_presigmoid.offset, C.sizeof(_lib.Gemm), _lib.Gemm.precision.offset,
-            _lib.Gemm.b_kshift_batch.offset, C.sizeof(_lib.Dims), _lib.Gemm.cu_budget.offset]
+            _lib.Gemm.b_kshift_batch.offset, C.sizeof(_lib.Dims), _lib.Gemm.cu_budget.offset, _lib.Gemm.res_off.offset,
+            _lib.Gemm.mask_batch.offset, _lib.Gemm.b_seg_off.offset]
     assert got == want, (got, want)
 
 
