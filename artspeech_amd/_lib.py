@@ -51,7 +51,7 @@ class Gemm(C.Structure):
                 ("colsum_batch", C.c_int64), ("a_off", C.c_void_p), ("b_off", C.c_void_p), ("c_off", C.c_void_p),
                 ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32), ("cu_budget", C.c_int32),
                 ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_batch", C.c_int64), ("res_off", C.c_void_p),
-                ("mask", C.c_void_p), ("mask_ld", C.c_int64), ("mask_batch", C.c_int64),
+                ("mask_bits", C.c_void_p), ("mask_batch", C.c_int64), ("relu_bits", C.c_void_p), ("relu_bits_batch", C.c_int64),
                 ("k_seg", C.c_int32), ("a_seg_off", C.c_void_p), ("b_seg_off", C.c_void_p)]
 
 

@@ -38,9 +38,10 @@ struct GemmK {
     float* colsum; long colsum_batch;
     // grouped batches: per-batch element offsets (device arrays) override the linear batch strides
     const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
-    // optional epilogue operands: C = mask > 0 ? act(acc + bias + res) : 0 (as_gemm.res / .mask)
+    // optional extra operands (as_gemm.res / .mask_bits / .relu_bits): C = keep ? act(res + acc + bias) : 0
     const float* res; long res_ld, res_batch; const long* res_off;
-    const float* mask; long mask_ld, mask_batch;
+    const unsigned* mask_bits; long mask_batch;
+    unsigned* relu_bits; long relu_bits_batch;
     // optional segmented reduction (as_gemm.k_seg): per (batch, segment) element offsets of the A rows and the B panel
     int k_seg; const long* a_seg_off; const long* b_seg_off;
 };
@@ -163,7 +164,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ s, int i, int k)
     return KC ? s[i * (BK + 1) + k] : s[k * BI + i];
 }
 
-// EXT: the instantiation that knows the optional epilogue operands (res / mask) and the segmented reduction; the plain one
+// EXT: the instantiation that knows the optional extra operands (res / mask_bits / relu_bits) and the segmented reduction; the plain one
 // carries neither (its register budget at three workgroups per CU has no room for them).
 template <int BM, int BN, bool A_KC, bool B_KC, bool FAST, bool EXT = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_kernel(GemmK g) {
@@ -234,12 +235,47 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         float* C = w.C;
         const int m0 = w.m0, n0 = w.n0, bz = w.bz, kbeg = w.kbeg, kend = w.kend;
         f32x16 acc[TM][TN];
+        unsigned mw[TM][TN];   // EXT: the ReLU-mask words of this lane's rows (lane l31 & 15 holds the word of accumulator row r = l31 & 15)
+        if (EXT && g.res != nullptr) {
+            // the residual is the accumulators' initial value: 64 loads into the registers the products will be added to, in
+            // flight while the operand tiles are staged through LDS -- no extra registers, no epilogue loads (an epilogue
+            // that fetches it has to interleave loads with its stores, and vector memory operations retire in order:
+            // measured 1281-1393 us against 945 for the 110 x [6400 x 256 x 256] launch, 834 without a residual).
+            // 32-bit element offsets from a wave-uniform base (the host checks the extents): an address is one VGPR
+            const float* res = g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch);
+            const unsigned res_ld = (unsigned)g.res_ld;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned colc = (unsigned)min(n0 + wn * WN + j * 32 + l31, g.N - 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = (unsigned)min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                        acc[i][j][r] = res[row * res_ld + colc];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        const unsigned ncb = (unsigned)(g.N + 31) >> 5;   // mask / ReLU-bit words per row
+        if (EXT && g.mask_bits != nullptr) {
+            const unsigned* mb = g.mask_bits + (long)bz * g.mask_batch;
+            const int r = l31 & 15;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned row = (unsigned)min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    const unsigned cb = min((unsigned)(n0 + wn * WN + j * 32) >> 5, ncb - 1);
+                    mw[i][j] = mb[row * ncb + cb];
+                }
+        }
         const int nk = (kend - kbeg + BK - 1) / BK;
         const bool do_cs = !EXT && !A_KC && g.colsum != nullptr && w.tn_idx == 0 && tid < BM;
         float cs_acc = 0.f;
@@ -283,7 +319,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         const int ks = w.ks, xy = w.xy;
         if (more) {
             w = decode(work);
-            if (!EXT) load_tiles(w, w.kbeg);   // (EXT: behind the epilogue, whose own operand loads need the registers)
+            load_tiles(w, w.kbeg);
         }
 
         // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -360,40 +396,41 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         if (final_store) {
             if (do_cs && m0 + tid < g.M) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = cs_acc;
             const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
-            if (EXT) {   // (the one epilogue of the extended instantiation: bias, ReLU, residual, mask)
-                // residual / ReLU-mask epilogue: the extra operands of four output rows are requested together, then the
-                // four results leave (a lane's accesses are 128-byte-coalesced across the 32 lanes of a column block).
-                // 32-bit element offsets from wave-uniform bases (the host checks the extents): an address is one VGPR
-                const float* res = g.res ? g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch) : nullptr;
-                const float* msk = g.mask ? g.mask + (long)bz * g.mask_batch : nullptr;
-                const unsigned res_ld = (unsigned)g.res_ld, mask_ld = (unsigned)g.mask_ld, ldc = (unsigned)g.ldc;
+            if (EXT) {   // (the one epilogue of the extended instantiation: bias, ReLU + its bit image, ReLU mask)
+                const unsigned ldc = (unsigned)g.ldc;
+                unsigned* rb_out = g.relu_bits ? g.relu_bits + (long)bz * g.relu_bits_batch : nullptr;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = n0 + wn * WN + j * 32 + l31;
-                    const unsigned colc = (unsigned)min(col, g.N - 1);
-                    const float bj = bias ? bias[colc] : 0.f;
+                    const bool col_ok = col < g.N;
+                    const float bj = bias ? bias[min(col, g.N - 1)] : 0.f;
+                    const unsigned cb = (unsigned)(n0 + wn * WN + j * 32) >> 5;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) {
+                        const int row0 = m0 + wm * WM + i * 32 + 4 * lh;
+                        unsigned keep_word = 0u;    // ReLU bits: lane l31 == r keeps the word of accumulator row r
 #pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            float rv[4], mv[4];
-                            const int row0 = m0 + wm * WM + i * 32 + 4 * lh + 8 * h;   // r = 4 h + q: rows row0 + q
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const unsigned row = (unsigned)min(row0 + q, g.M - 1);
-                                rv[q] = res ? res[row * res_ld + colc] : 0.f;
-                                mv[q] = msk ? msk[row * mask_ld + colc] : 1.f;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            float v = acc[i][j][r] + bj;
+                            if (g.act == 1) v = as_relu(v);
+                            if (rb_out != nullptr) {
+                                const unsigned long long pos = __ballot(v > 0.f && col_ok);
+                                const unsigned word = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
+                                keep_word = l31 == r ? word : keep_word;
                             }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int row = row0 + q;
-                                float v = acc[i][j][h * 4 + q] + bj + rv[q];
-                                if (g.act == 1) v = as_relu(v);
-                                if (!(mv[q] > 0.f)) v = 0.f;
-                                if (row < g.M && col < g.N) C[(unsigned)row * ldc + (unsigned)col] = v;
+                            if (g.mask_bits != nullptr) {
+                                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mw[i][j], r);
+                                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)mw[i][j], 32 + r);
+                                if (!(((lh ? hi : lo) >> l31) & 1u)) v = 0.f;
                             }
-                            __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise requests all 128 operands first)
+                            if (row < g.M && col_ok) C[(unsigned)row * ldc + (unsigned)col] = v;
                         }
+                        if (rb_out != nullptr && l31 < 16) {
+                            const int row = row0 + (l31 & 3) + 8 * (l31 >> 2);
+                            if (row < g.M && cb < ncb) rb_out[(unsigned)row * ncb + cb] = keep_word;
+                        }
+                    }
                 }
             } else if (whole && !g.accumulate) {
                 float* c0 = C + (long)(m0 + wm * WM + 4 * lh) * g.ldc + n0 + wn * WN + l31;
@@ -439,7 +476,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
             }
         }
         if (!more) break;
-        if (EXT) load_tiles(w, w.kbeg);
     }
 }
 
@@ -687,7 +723,7 @@ int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
         const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);            \
     } while (0)
-    if (k.res || k.mask || k.k_seg > 0) {   // the extended instantiations (as_gemm_f32 has checked a_kc and float4-clean operands)
+    if (k.res || k.mask_bits || k.relu_bits || k.k_seg > 0) {   // the extended instantiations (as_gemm_f32 has checked a_kc and float4-clean operands)
 #define AS_GEMM_LAUNCH_EXT(BK_)                                                                      \
     do {                                                                                             \
         static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, true, BK_, true, true>);    \
@@ -698,7 +734,7 @@ int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
             if (b_kc) AS_GEMM_LAUNCH_EXT(true);
             else AS_GEMM_LAUNCH_EXT(false);
         } else {
-            AS_REQUIRE(false, AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg need a square tile");
+            AS_REQUIRE(false, AS_ERR_BAD_ARG, "as_gemm_f32: the extended operands need a square tile");
         }
 #undef AS_GEMM_LAUNCH_EXT
     } else if (fast) {
@@ -751,18 +787,20 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
     k.bias_off = (const long*)g->bias_off;
     k.res = g->res; k.res_ld = g->res_ld; k.res_batch = g->res_batch; k.res_off = (const long*)g->res_off;
-    k.mask = g->mask; k.mask_ld = g->mask_ld; k.mask_batch = g->mask_batch;
+    k.mask_bits = g->mask_bits; k.mask_batch = g->mask_batch; k.relu_bits = g->relu_bits; k.relu_bits_batch = g->relu_bits_batch;
     k.k_seg = g->k_seg; k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
-    const bool epi_ops = g->res || g->mask, segmented = g->k_seg > 0;
+    const bool epi_ops = g->res || g->mask_bits || g->relu_bits, segmented = g->k_seg > 0;
     AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && g->precision == 0 && (a_kc || b_kc)),
-               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg go with the general kernel only (no colsum, splitk_ws, accumulate, "
-               "split precision or weight-gradient shape)");
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg go with the general kernel only (no colsum, splitk_ws, "
+               "accumulate, split precision or weight-gradient shape)");
+    AS_REQUIRE(!g->relu_bits || g->act == 1, AS_ERR_BAD_ARG, "as_gemm_f32: relu_bits is the bit image of a ReLU epilogue (act == 1)");
     AS_REQUIRE(!(epi_ops || segmented) || (a_kc && aligned16(g->A) && aligned16(g->B) && a_ld % 4 == 0 && b_ld % 4 == 0 && g->K % 4 == 0 &&
-                                           (b_kc || g->N % 4 == 0) && g->act <= 1),
-               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg need a reduction-contiguous A, float4-clean operands and act <= 1");
-    AS_REQUIRE(!(epi_ops || segmented) || ((long)g->M * g->ldc < (1L << 31) && (long)g->M * g->res_ld < (1L << 31) &&
-                                           (long)g->M * g->mask_ld < (1L << 31)),
-               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask / k_seg address one batch member's C, res and mask with 32-bit offsets");
+                                           (b_kc || g->N % 4 == 0) && g->act <= 1 && (g->a_off || segmented || g->a_batch % 4 == 0) &&
+                                           (g->b_off || segmented || g->b_batch % 4 == 0)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg need a reduction-contiguous A, float4-clean operands "
+               "and act <= 1");
+    AS_REQUIRE(!(epi_ops || segmented) || ((long)g->M * g->ldc < (1L << 31) && (long)g->M * g->res_ld < (1L << 31)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg address one batch member's C and res with 32-bit offsets");
     AS_REQUIRE(!segmented || (g->k_seg % BK == 0 && g->K % g->k_seg == 0 && g->a_seg_off && g->b_seg_off && g->b_kT == 0),
                AS_ERR_BAD_ARG, "as_gemm_f32: k_seg=%d needs a multiple of %d that divides K=%d and both segment tables", g->k_seg, BK, g->K);
     const bool grouped = g->a_off || g->b_off || g->c_off || g->bias_off;

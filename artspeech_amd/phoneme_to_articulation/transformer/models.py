@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from ... import _lib
 from ..encoder_decoder.models import _build_views, _numel, _reference_init
-from .ops import Attention, ChannelBlocks, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize
+from .ops import Attention, ChannelBlocks, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize, channel_blocks_forward
 
 FF_DIM = 2048      # nn.TransformerEncoderLayer's default dim_feedforward (not overridden by the reference, :309-313)
 ENC_DROPOUT = 0.1  # ... and its default dropout: the model's `dropout` argument does not reach the encoder
@@ -328,16 +328,11 @@ class ArtSpeechTransformer(nn.Module):
             return ChannelBlocks.apply(xhat_tgt, xhat_src, P[n + "q_w"], P[n + "q_b"], P[n + "k_w"], P[n + "k_b"], P[n + "v_w"],
                                        P[n + "v_b"], P[n + "in_w"], P[n + "in_b"], P[n + "o_w"], P[n + "o_b"], P[n + "ln_w"],
                                        P[n + "ln_b"], attn_mask, kpm, (tgt_idx, src_idx, B, self.num_heads, cat))
-        # generate(): the memory side (k2, v2) was projected once per call (_memory_kv); inference only
-        assert cat is None and not torch.is_grad_enabled()
-        ident = tuple(range(self._group_sizes[group]))
-        wq, bq = self._fold(P[n + "q_w"], P[n + "ln_w"], P[n + "ln_b"], P[n + "q_b"])
-        q = GroupedLinear.apply(xhat_tgt, wq, bq, tgt_idx, True)
-        in_w, in_b = P[n + "in_w"], P[n + "in_b"]
-        q2 = GroupedLinear.apply(q, in_w[:, :d], in_b[:, :d], ident, False)
-        ctx = Attention.apply(q2, kv[0], kv[1], attn_mask, kpm, B, self.num_heads)
-        o = GroupedLinear.apply(ctx, P[n + "o_w"], P[n + "o_b"], ident, False)
-        return q + o  # the residual is the PROJECTED query (:98)
+        # generate(): the memory side (k2, v2) was projected once per call (_memory_kv); inference only, same arithmetic
+        assert not torch.is_grad_enabled()
+        return channel_blocks_forward(xhat_tgt, None, P[n + "q_w"], P[n + "q_b"], None, None, None, None, P[n + "in_w"], P[n + "in_b"],
+                                      P[n + "o_w"], P[n + "o_b"], P[n + "ln_w"], P[n + "ln_b"], attn_mask, kpm,
+                                      (tgt_idx, src_idx, B, self.num_heads, cat), False, kv2=kv)[0]
 
     def _decoder_layer(self, l, x, mem_hat, tgt_mask, memory_mask, tgt_kpm, mem_kpm, B, mem_kv=None, last_only=False):
         """MultiChannelTransformerDecoderLayer.forward (:216-277) on channel-major x [A, R, d].  last_only (generate()'s last

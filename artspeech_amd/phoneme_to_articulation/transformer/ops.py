@@ -330,6 +330,88 @@ def _ptr(t, off_floats=0):
     return t.data_ptr() + 4 * off_floats
 
 
+def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm, cfg, training,
+                           kv2=None):
+    """Forward of ChannelBlocks (see there).  kv2 = (k2, v2) [G, Rs, d] each: the in-projected key / value side computed
+    elsewhere (generate(): the memory side of the cross-attention blocks, once per call) -- inference only; xs is unused
+    then.  Returns (out, tensors for the backward or None, meta)."""
+    tgt, src, B, heads, cat = cfg
+    xt = _c(xt)
+    q_w, q_b, in_w, in_b, o_w, o_b, ln_w, ln_b = (_c(p) for p in (q_w, q_b, in_w, in_b, o_w, o_b, ln_w, ln_b))
+    G, d = q_w.shape[0], q_w.shape[-1]
+    Ct, R, _ = xt.shape
+    dev = xt.device
+    L, st = _lib.lib(), _lib.stream_ptr()
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    assert kv2 is None or not training
+    if kv2 is None:
+        xs, k_w, k_b, v_w, v_b = (_c(p) for p in (xs, k_w, k_b, v_w, v_b))
+        Cs, Rs, _ = xs.shape
+        folds = ((q_w, q_b), (k_w, k_b), (v_w, v_b))
+    else:
+        Rs = kv2[0].shape[1]
+        folds = ((q_w, q_b),)
+    # LayerNorm affine folded into the three pre-projections
+    W3, b3 = new(3, G, d, d), new(3, G, d)
+    for j, (w, b) in enumerate(folds):
+        _lib.check(L.as_fold_ln(_lib.ptr(w), _lib.ptr(ln_w), _lib.ptr(ln_b), _lib.ptr(b), _ptr(W3, j * G * d * d), _ptr(b3, j * G * d), G,
+                                d, d, st), "as_fold_ln")
+    same = R == Rs and kv2 is None
+    pre = new(3, G, R, d) if same else None          # q, k, v (after the ReLU), one buffer when the row counts agree
+    q = pre[0] if same else new(G, R, d)
+    t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])
+    # training: the ReLUs leave their bit images (1 bit per element) for the backward's masks
+    ncb = (d + 31) // 32
+    qbits = torch.empty((G, R, ncb), dtype=torch.int32, device=dev) if training else None
+    kvbits = torch.empty((2 * G, Rs, ncb), dtype=torch.int32, device=dev) if training else None
+    bq = dict(relu_bits=qbits, relu_bits_batch=R * ncb, precision=0) if training else {}
+    bkv = dict(relu_bits=kvbits, relu_bits_batch=Rs * ncb, precision=0) if training else {}
+    _gemm(A=xt, B=W3, C=q, bias=b3, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_off=t_off, b_batch=d * d,
+          c_batch=R * d, bias_batch=d, act=1, **bq)
+    # MHA in-projection: slice j of the stacked [G, 3d, d] weight, read in place
+    w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
+    bi_off = _table(dev, ("inb", G, d), lambda: [g * 3 * d + j * d for j in range(3) for g in range(G)])
+    p2 = new(3, G, R, d) if same else None
+    q2 = p2[0] if same else new(G, R, d)
+    kv = None
+    if kv2 is None:
+        kv = pre[1:] if same else new(2, G, Rs, d)
+        s_off2 = _table(dev, ("src2", src, Rs * d), lambda: [s * Rs * d for s in src] * 2)
+        _gemm(A=xs, B=_ptr(W3, G * d * d), C=kv, bias=_ptr(b3, G * d), M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G,
+              a_off=s_off2, b_batch=d * d, c_batch=Rs * d, bias_batch=d, act=1, **bkv)
+        kv2 = p2[1:] if same else new(2, G, Rs, d)
+    if same:
+        _gemm(A=pre, B=in_w, C=p2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=3 * G, a_batch=R * d,
+              b_off=w_off, c_batch=R * d, bias_off=bi_off)
+    else:
+        _gemm(A=q, B=in_w, C=q2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d,
+              b_batch=3 * d * d, c_batch=R * d, bias_batch=3 * d)
+        if kv is not None:
+            _gemm(A=kv, B=in_w, C=kv2, bias=in_b, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G, a_batch=Rs * d,
+                  b_off=w_off[G:], c_batch=Rs * d, bias_off=bi_off[G:])
+    att, att_saved, scale = attention_forward(q2, _c(kv2[0]), _c(kv2[1]), attn_mask, kpm, B, heads, training)
+    # out = q + out_proj(ctx): the residual is added by the GEMM's epilogue in the reference's order ((sum + bias) + q: as an
+    # initial accumulator value it would cost nothing, but the forward's rounding noise grows -- the full-width contours
+    # left the 1e-4 band, tests/test_gpu_transformer.py), the result goes straight into its final layout
+    if cat is not None:
+        A_, per = cat
+        assert A_ * per == G
+        out = new(A_, R, per * d)
+        ldo = per * d
+        c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
+        lay = dict(c_off=c_off)
+    else:
+        out = new(G, R, d)
+        ldo = d
+        lay = dict(c_batch=R * d)
+    _gemm(A=att, B=o_w, C=out, bias=o_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=ldo, batch=G, a_batch=R * d, b_batch=d * d,
+          bias_batch=d, res=q, res_ld=d, res_batch=R * d, precision=0, **lay)
+    if not training:
+        return out, None, None
+    return (out, (xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits, *att_saved),
+            (tgt, src, B, heads, cat, scale, ldo))
+
+
 class ChannelBlocks(torch.autograd.Function):
     """One GROUP of ChannelProcessingLayers (reference transformer/models.py:37-100; the A self blocks, the A*(A-1)
     interaction blocks or the A cross-attention blocks of a decoder layer, :165-277) as ONE autograd node with a
@@ -344,79 +426,30 @@ class ChannelBlocks(torch.autograd.Function):
     concatenation over the other channels that ChannelInteractionsLayer builds (:133-162) -- else block-major [G, R, d].
 
     What the fusion buys over one autograd node per Linear (measured): the residual is added by the
-    out-projection GEMM's epilogue; in the backward the ReLU masks and the residual's gradient are applied by the
-    epilogue of the in-projection's input-gradient GEMM (no pass over the [G, R, d] activations in between), the k and v
+    out-projection GEMM's epilogue; in the backward the residual's gradient starts the accumulators of the
+    in-projection's input-gradient GEMM, whose epilogue applies the ReLU masks from 1-bit images the forward GEMMs left
+    (no pass over the [G, R, d] activations in between), the k and v
     sides run as one batch of 2G, the in-projection reads and writes the stacked [G, 3d, d] weight / gradient in place, and
     the per-channel input gradients are sums over the blocks of a channel INSIDE one segmented GEMM (as_gemm.k_seg)."""
 
     @staticmethod
     def forward(ctx, xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm, cfg):
-        tgt, src, B, heads, cat = cfg
-        xt, xs = _c(xt), _c(xs)
-        q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b = (_c(p) for p in (q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w,
-                                                                                            o_b, ln_w, ln_b))
-        G, d = q_w.shape[0], q_w.shape[-1]
-        (Ct, R, _), (Cs, Rs, _) = xt.shape, xs.shape
-        dev = xt.device
-        L, st = _lib.lib(), _lib.stream_ptr()
         training = any(ctx.needs_input_grad)
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        # LayerNorm affine folded into the three pre-projections
-        W3, b3 = new(3, G, d, d), new(3, G, d)
-        for j, (w, b) in enumerate(((q_w, q_b), (k_w, k_b), (v_w, v_b))):
-            _lib.check(L.as_fold_ln(_lib.ptr(w), _lib.ptr(ln_w), _lib.ptr(ln_b), _lib.ptr(b), _ptr(W3, j * G * d * d), _ptr(b3, j * G * d), G,
-                                    d, d, st), "as_fold_ln")
-        same = R == Rs
-        pre = new(3, G, R, d) if same else None          # q, k, v (after the ReLU), one buffer when the row counts agree
-        q = pre[0] if same else new(G, R, d)
-        kv = pre[1:] if same else new(2, G, Rs, d)
-        t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])
-        s_off2 = _table(dev, ("src2", src, Rs * d), lambda: [s * Rs * d for s in src] * 2)
-        _gemm(A=xt, B=W3, C=q, bias=b3, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_off=t_off, b_batch=d * d,
-              c_batch=R * d, bias_batch=d, act=1)
-        _gemm(A=xs, B=_ptr(W3, G * d * d), C=kv, bias=_ptr(b3, G * d), M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G,
-              a_off=s_off2, b_batch=d * d, c_batch=Rs * d, bias_batch=d, act=1)
-        # MHA in-projection: slice j of the stacked [G, 3d, d] weight, read in place
-        w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
-        bi_off = _table(dev, ("inb", G, d), lambda: [g * 3 * d + j * d for j in range(3) for g in range(G)])
-        p2 = new(3, G, R, d) if same else None
-        q2 = p2[0] if same else new(G, R, d)
-        kv2 = p2[1:] if same else new(2, G, Rs, d)
-        if same:
-            _gemm(A=pre, B=in_w, C=p2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=3 * G, a_batch=R * d,
-                  b_off=w_off, c_batch=R * d, bias_off=bi_off)
-        else:
-            _gemm(A=q, B=in_w, C=q2, bias=in_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d,
-                  b_batch=3 * d * d, c_batch=R * d, bias_batch=3 * d)
-            _gemm(A=kv, B=in_w, C=kv2, bias=in_b, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G, a_batch=Rs * d,
-                  b_off=w_off[G:], c_batch=Rs * d, bias_off=bi_off[G:])
-        att, att_saved, scale = attention_forward(q2, kv2[0], kv2[1], attn_mask, kpm, B, heads, training)
-        # out = q + out_proj(ctx): the residual goes in with the GEMM's epilogue, the result straight into its final layout
-        if cat is not None:
-            A_, per = cat
-            assert A_ * per == G
-            out = new(A_, R, per * d)
-            ldo = per * d
-            c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
-            lay = dict(c_off=c_off)
-        else:
-            out = new(G, R, d)
-            ldo, c_off = d, None
-            lay = dict(c_batch=R * d)
-        _gemm(A=att, B=o_w, C=out, bias=o_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=ldo, batch=G, a_batch=R * d, b_batch=d * d,
-              bias_batch=d, res=q, res_ld=d, res_batch=R * d, precision=0, **lay)
+        out, saved, meta = channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm,
+                                                  cfg, training)
         if training:
-            ctx.save_for_backward(xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, *att_saved)
-            ctx.meta = (tgt, src, B, heads, cat, scale, ldo)
+            ctx.save_for_backward(*saved)
+            ctx.meta = meta
         return out
 
     @staticmethod
     def backward(ctx, dout):
         saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
-        xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att = saved[:13]
-        att_saved = saved[13:]
+        xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits = saved[:15]
+        att_saved = saved[15:]
         tgt, src, B, heads, cat, scale, ldo = ctx.meta
         G, d = q_w.shape[0], q_w.shape[-1]
+        ncb = (d + 31) // 32
         (Ct, R, _), (Cs, Rs, _) = xt.shape, xs.shape
         dev = xt.device
         L, st = _lib.lib(), _lib.stream_ptr()
@@ -452,9 +485,9 @@ class ChannelBlocks(torch.autograd.Function):
         dq, dkv = new(G, R, d), new(2, G, Rs, d)
         w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
         _gemm(A=dq2, B=in_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=3 * d * d,
-              c_batch=R * d, res=dout, res_ld=ldo, mask=q, mask_ld=d, mask_batch=R * d, precision=0, **r_lay)
+              c_batch=R * d, res=dout, res_ld=ldo, res_init=1, mask_bits=qbits, mask_batch=R * ncb, precision=0, **r_lay)
         _gemm(A=dkv2, B=in_w, C=dkv, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d, b_off=w_off[G:],
-              c_batch=Rs * d, mask=kv, mask_ld=d, mask_batch=Rs * d, precision=0)
+              c_batch=Rs * d, mask_bits=kvbits, mask_batch=Rs * ncb, precision=0)
         del dp2, dq2, dkv2
         # ---- pre-projections: gradients of the folded weights, unfolded onto (W, gamma, beta)
         t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])

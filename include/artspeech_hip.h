@@ -214,15 +214,23 @@ typedef struct as_gemm {
        have (0 = the whole chip), e.g. 192 while a 64-workgroup recurrence kernel runs beside it on another stream; only the
        split-K factor depends on it, never the result's summation order for a given factor. */
     int32_t cu_budget;
-    /* optional epilogue operands of the general kernel (forward / input-gradient shapes; refused together with colsum,
-       splitk_ws-driven split-K and the weight-gradient kernel):  C = mask > 0 ? act(acc + bias + res) : 0.
-       res  [.][M][N] through (res_ld, res_batch | res_off): a residual added before the activation -- the `q + out_proj(ctx)`
-            of a ChannelProcessingLayer (transformer/models.py:98) written by the out-projection GEMM itself, or in the
-            backward the gradient arriving over that residual, added to the in-projection's input gradient;
-       mask [.][M][N] through (mask_ld, mask_batch): the saved OUTPUT of a ReLU whose backward this GEMM's result goes
-            through (dz = dy * [y > 0], models.py:47-60 through autograd) -- no separate pass over the activations. */
+    /* optional extra operands of the general kernel (forward / input-gradient shapes with a reduction-contiguous A; refused
+       together with colsum, splitk_ws, accumulate, split precision and weight-gradient shapes):
+           C = keep ? act(res + acc + bias) : 0
+       res       [.][M][N] through (res_ld, res_batch | res_off): the INITIAL VALUE of the accumulators (loaded while the
+                 first operand tiles are staged: no extra pass, no epilogue loads); the sum is (res + sum_k in k order) +
+                 bias.  In the backward of a ChannelProcessingLayer (transformer/models.py:98) the gradient that arrives
+                 over the residual `q + out_proj(ctx)` joins the in-projection's input gradient this way.  Every partial sum
+                 carries the residual's magnitude, so the product's rounding error grows with |res| / |sum|: meant for
+                 gradients; the forward's residual is added by the LayerNorm that consumes it (as_layernorm_fwd_blockres).
+       relu_bits out, with act == 1: one bit per output element, [.][M][ceil(N / 32)] 32-bit words (bit n % 32 of word
+                 n / 32 of a row: result > 0), batch stride relu_bits_batch words -- what the backward of the ReLU needs;
+       mask_bits in: such a bit image; elements whose bit is clear are stored as 0 (dz = dy * [y > 0], models.py:47-60
+                 through autograd): the ReLU backward rides in the epilogue of the GEMM that produces dy, reading 1/32 of
+                 what a pass over the saved activations would. */
     const float* res; int64_t res_ld, res_batch; const int64_t* res_off;
-    const float* mask; int64_t mask_ld, mask_batch;
+    const uint32_t* mask_bits; int64_t mask_batch;
+    uint32_t* relu_bits; int64_t relu_bits_batch;
     /* optional SEGMENTED reduction (a_k == 1 input-gradient / forward shapes of the general kernel): the reduction index is
        cut into K / k_seg segments of k_seg (a multiple of 32) and segment s of batch member g reads its A rows from
        A + a_seg_off[g * nseg + s] and its B panel from B + b_seg_off[g * nseg + s] (element offsets, multiples of 4; the

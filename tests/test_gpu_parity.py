@@ -178,9 +178,10 @@ def test_gemm_batched_strided_and_shift(dev):
 
 @pytest.mark.parametrize("R,d,G,big", [(200, 64, 6, False), (1500, 256, 12, False), (77, 32, 3, False), (6400, 256, 6, True)])
 def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
-    """as_gemm.res / .mask / .k_seg (the fused pieces of a ChannelProcessingLayer group, transformer/models.py:70-100 and its
-    autograd): out-projection + residual written into the concatenated layout; in-projection input gradient + residual
-    gradient through the ReLU mask; per-channel input gradients summed over the blocks of a channel by ONE segmented GEMM."""
+    """as_gemm.res / .relu_bits / .mask_bits / .k_seg (the fused pieces of a ChannelProcessingLayer group,
+    transformer/models.py:70-100 and its autograd): out-projection + residual written into the concatenated layout; a ReLU's
+    bit image; in-projection input gradient + residual gradient through that mask; per-channel input gradients summed
+    over the blocks of a channel by ONE segmented GEMM."""
     from artspeech_amd import _lib
     L = _lib.lib()
     rng = np.random.RandomState(R + d + G)
@@ -204,25 +205,53 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
     t_ctx, t_w, t_b, t_q = T_(ctx, dev), T_(w, dev), T_(b, dev), T_(q, dev)
     out = torch.full((A_, R, per * d), float("nan"), device=dev)
     coff = tbl([c * R * per * d + j * d for c in range(A_) for j in range(per)])
-    call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
-         bias_batch=d, c_off=coff, res=t_q, res_ld=d, res_batch=R * d)
     ref = q + np.einsum("grk,gnk->grn", ctx.astype(np.float64), w) + b[:, None]
     ref_cat = ref.reshape(A_, per, R, d).transpose(0, 2, 1, 3).reshape(A_, R, per * d)
-    assert_close(out.cpu().numpy(), ref_cat, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="out-projection + residual, concatenated")
+    for res_init in (0, 1):   # added by the epilogue (reference order) / initial value of the accumulators
+        out.fill_(float("nan"))
+        call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
+             bias_batch=d, c_off=coff, res=t_q, res_ld=d, res_batch=R * d, res_init=res_init)
+        assert_close(out.cpu().numpy(), ref_cat, rtol=2e-5, atol=2e-5 * np.sqrt(d), what=f"out-projection + residual ({res_init}), concatenated")
+    if not big:   # the late residual reproduces (sum + bias) + res bit for bit: the plain kernel's result + a float add
+        plain = torch.empty((G, R, d), device=dev)
+        call(A=t_ctx, B=t_w, C=plain, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d, b_batch=d * d,
+             bias_batch=d, c_batch=R * d)
+        late = torch.empty((G, R, d), device=dev)
+        call(A=t_ctx, B=t_w, C=late, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d, b_batch=d * d,
+             bias_batch=d, c_batch=R * d, res=t_q, res_ld=d, res_batch=R * d)
+        assert torch.equal(late, plain + t_q)
 
-    # (2) dq[g] = (dq2[g] w[g] + dout_cat[block g]) * [q[g] > 0]: NN product, residual read through the table, ReLU mask
+    # (2) the ReLU's bit image from a forward GEMM: bit n % 32 of word n / 32 of a row = (result > 0)
+    xin = rng.randn(G, R, d).astype(np.float32)
+    t_x = T_(xin, dev)
+    ncb = (d + 31) // 32
+    y = torch.full((G, R, d), float("nan"), device=dev)
+    bits = torch.zeros((G, R, ncb), dtype=torch.int32, device=dev)
+    call(A=t_x, B=t_w, C=y, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d, b_batch=d * d, c_batch=R * d,
+         bias_batch=d, act=1, relu_bits=bits, relu_bits_batch=R * ncb)
+    ref = np.maximum(np.einsum("grk,gnk->grn", xin.astype(np.float64), w) + b[:, None], 0)
+    assert_close(y.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="forward + relu (extended kernel)")
+    yh = y.cpu().numpy()
+    words = bits.cpu().numpy().view(np.uint32)
+    got = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(G, R, ncb * 32)[..., :d].astype(bool)
+    assert (got == (yh > 0)).all(), "ReLU bit image"
+    if d % 32:
+        assert (((words[..., -1] >> np.uint32(d % 32)) == 0)).all(), "bits beyond N are clear"
+
+    # (3) dq[g] = (dq2[g] w[g] + dout_cat[block g]) * [y[g] > 0]: NN product, the residual gradient read through the table as the
+    # accumulators' initial value, ReLU mask from the bit image
     dq2 = rng.randn(G, R, d).astype(np.float32)
     dcat = rng.randn(A_, R, per * d).astype(np.float32)
     t_dq2, t_dcat = T_(dq2, dev), T_(dcat, dev)
     dq = torch.full((G, R, d), float("nan"), device=dev)
     call(A=t_dq2, B=t_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=d * d, c_batch=R * d,
-         res=t_dcat, res_ld=per * d, res_off=coff, mask=t_q, mask_ld=d, mask_batch=R * d)
+         res=t_dcat, res_ld=per * d, res_off=coff, res_init=1, mask_bits=bits, mask_batch=R * ncb)
     dres = dcat.reshape(A_, R, per, d).transpose(0, 2, 1, 3).reshape(G, R, d)
-    ref = (np.einsum("grn,gnk->grk", dq2.astype(np.float64), w) + dres) * (q > 0)
+    ref = (np.einsum("grn,gnk->grk", dq2.astype(np.float64), w) + dres) * (yh > 0)
     assert_close(dq.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="input gradient + residual gradient, masked")
-    assert (dq.cpu().numpy()[q <= 0] == 0).all()
+    assert (dq.cpu().numpy()[yh <= 0] == 0).all()
 
-    # (3) dx[c] = sum over the blocks g with src[g] = c of dz[g] w[g]: one GEMM with K = per * d in segments of d
+    # (4) dx[c] = sum over the blocks g with src[g] = c of dz[g] w[g]: one GEMM with K = per * d in segments of d
     if d % 32 == 0:
         src = [(g * 7 + 1) % A_ for g in range(G)] if A_ > 1 else [0] * G
         src = sorted(src)                                     # any grouping; here `per` blocks per channel
