@@ -556,12 +556,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ xhat,
                                                             float* __restrict__ rstd, long rows, int D, long group_rows,
-                                                            float eps) {
+                                                            float eps, int res_block = 0, long res_rows = 0) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + row * D;
-    const float* rr = res ? res + row * D : nullptr;
+    // res_block > 0 (as_layernorm_fwd_blockres): x rows are [channel][res_rows][per * res_block] -- the concatenation of `per`
+    // blocks of res_block features -- and the residual is block-major, res[(channel * per + j)][row in channel][res_block]
+    const float* rr = res ? res + (res_block > 0 ? ((row / res_rows) * (D / res_block) * res_rows + row % res_rows) * res_block : row * D) : nullptr;
+    const long res_jstride = res_block > 0 ? res_rows * res_block - res_block : 0;   // block j's row starts j * res_rows * res_block further
     // group_rows > 0: consecutive blocks of rows share a parameter set; < 0: parameter set = row % (-group_rows)
     const long g = group_rows > 0 ? row / group_rows : (group_rows < 0 ? row % (-group_rows) : 0);
     float v[NW], ga[NW], be[NW];
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int c = 0; c < NW; ++c) {
         const int i = lane + 64 * c;
         const int ic = i < D ? i : D - 1;
-        v[c] = rr ? xr[ic] + rr[ic] : xr[ic];
+        v[c] = rr ? xr[ic] + rr[ic + (res_block > 0 ? (ic / res_block) * res_jstride : 0)] : xr[ic];
         ga[c] = gamma ? gamma[g * D + ic] : 1.f;
         be[c] = gamma ? beta[g * D + ic] : 0.f;
     }
@@ -872,6 +875,26 @@ extern "C" int as_layernorm_fwd(const float* x, const float* res, const float* g
     else AS_LN_FWD(44);
 #undef AS_LN_FWD
     AS_LAUNCH_CHECK("as_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int as_layernorm_fwd_blockres(const float* x, const float* res, float* xhat, float* rstd, int32_t channels, int64_t rows,
+                                         int32_t per, int32_t block, void* stream) {
+    AS_REQUIRE(x && res && xhat && channels > 0 && rows > 0 && per > 0 && block > 0, AS_ERR_BAD_ARG, "as_layernorm_fwd_blockres: bad argument");
+    const int D = per * block;
+    AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd_blockres: row length %d > %d", D, 64 * 44);
+    const long total = (long)channels * rows;
+#define AS_LN_FWD(NW)                                                                                                              \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<NW>, dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res, (const float*)nullptr, \
+                       (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block, (long)rows)
+    if (D <= 64) AS_LN_FWD(1);
+    else if (D <= 128) AS_LN_FWD(2);
+    else if (D <= 256) AS_LN_FWD(4);
+    else if (D <= 512) AS_LN_FWD(8);
+    else if (D <= 1024) AS_LN_FWD(16);
+    else AS_LN_FWD(44);
+#undef AS_LN_FWD
+    AS_LAUNCH_CHECK("as_layernorm_fwd_blockres");
     return 0;
 }
 

@@ -30,7 +30,8 @@ import torch.nn.functional as F
 
 from ... import _lib
 from ..encoder_decoder.models import _build_views, _numel, _reference_init
-from .ops import Attention, ChannelBlocks, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize, channel_blocks_forward
+from .ops import (Attention, ChannelBlocks, FoldLN, GroupedLinear, Heads, LayerNormAffine, Normalize, NormalizeRes,
+                  channel_blocks_forward)
 
 FF_DIM = 2048      # nn.TransformerEncoderLayer's default dim_feedforward (not overridden by the reference, :309-313)
 ENC_DROPOUT = 0.1  # ... and its default dropout: the model's `dropout` argument does not reach the encoder
@@ -319,8 +320,9 @@ class ArtSpeechTransformer(nn.Module):
                 GroupedLinear.apply(v, in_w[:, 2 * d:], in_b[:, 2 * d:], ident, False))
 
     def _blocks(self, l, group, xhat_tgt, xhat_src, attn_mask, kpm, B, kv=None, cat=None):
-        """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> [G, R, d], or with
-        cat = (A, per) the concatenation over the `per` blocks of each channel, [A, R, per * d] (:133-162)."""
+        """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> (out, q): the out-projections
+        [G, R, d] -- with cat = (A, per) concatenated over the `per` blocks of each channel, [A, R, per * d] (:133-162) -- and
+        the projected queries, the residual (:98) that the LayerNorm consuming the pair adds."""
         P, d = self.P, self.embed_dim
         tgt_idx, src_idx = self._groups[group]
         n = f"dec{l}_{group}_"
@@ -332,7 +334,7 @@ class ArtSpeechTransformer(nn.Module):
         assert not torch.is_grad_enabled()
         return channel_blocks_forward(xhat_tgt, None, P[n + "q_w"], P[n + "q_b"], None, None, None, None, P[n + "in_w"], P[n + "in_b"],
                                       P[n + "o_w"], P[n + "o_b"], P[n + "ln_w"], P[n + "ln_b"], attn_mask, kpm,
-                                      (tgt_idx, src_idx, B, self.num_heads, cat), False, kv2=kv)[0]
+                                      (tgt_idx, src_idx, B, self.num_heads, cat), False, kv2=kv)[:2]
 
     def _decoder_layer(self, l, x, mem_hat, tgt_mask, memory_mask, tgt_kpm, mem_kpm, B, mem_kv=None, last_only=False):
         """MultiChannelTransformerDecoderLayer.forward (:216-277) on channel-major x [A, R, d].  last_only (generate()'s last
@@ -342,8 +344,7 @@ class ArtSpeechTransformer(nn.Module):
         R = x.shape[1]
         n = f"dec{l}_"
         xhat = Normalize.apply(x)
-        proc = self._blocks(l, "proc", xhat, xhat, tgt_mask, tgt_kpm, B)                    # [A, R, d]
-        phat = Normalize.apply(proc)
+        phat = NormalizeRes.apply(*self._blocks(l, "proc", xhat, xhat, tgt_mask, tgt_kpm, B), None)   # [A, R, d]
         if last_only:
             assert tgt_mask is None and tgt_kpm is None
             phat_q = phat.view(A, B, R // B, d)[:, :, -1].contiguous()                        # [A, B, d]: one query row per utterance
@@ -352,9 +353,9 @@ class ArtSpeechTransformer(nn.Module):
             phat_q = phat
         cat = self._blocks(l, "inter", phat_q, phat, tgt_mask, tgt_kpm, B, cat=(A, A - 1))   # [A, R, (A-1) d]: concat over the others
         wl, bl = self._fold(P[n + "il_w"], P[n + "il_ln_w"], P[n + "il_ln_b"], P[n + "il_b"])
-        inter = GroupedLinear.apply(Normalize.apply(cat), wl, bl, tuple(range(A)), True)      # [A, R, d]
+        inter = GroupedLinear.apply(NormalizeRes.apply(*cat, (A, A - 1)), wl, bl, tuple(range(A)), True)      # [A, R, d]
         inp = self._blocks(l, "input", Normalize.apply(inter), mem_hat, memory_mask, mem_kpm, B, kv=mem_kv)
-        y = LayerNormAffine.apply(inp, None, P[n + "ln2_w"], P[n + "ln2_b"])
+        y = LayerNormAffine.apply(*inp, P[n + "ln2_w"], P[n + "ln2_b"])
         wf, bf = self._fold(P[n + "ff_w"][None], P[n + "ff_ln_w"][None], P[n + "ff_ln_b"][None], P[n + "ff_b"][None])
         ff = GroupedLinear.apply(Normalize.apply(y).view(1, A * R, d), wf, bf, (0,), True).view(A, R, d)
         return y + ff

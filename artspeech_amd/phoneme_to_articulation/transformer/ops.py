@@ -111,6 +111,46 @@ class Normalize(torch.autograd.Function):
         return dx
 
 
+class NormalizeRes(torch.autograd.Function):
+    """x_hat = affine-free LayerNorm(x + res) -- the LayerNorm that consumes a block group's output adds the group's residual
+    (the projected queries, transformer/models.py:98), in the reference's order (sum + bias) + q.  cat = None: res has x's
+    layout.  cat = (A, per): x is the concatenated [A, R, per * d] output of the group and res the block-major
+    [A, per, R, d] queries (ChannelBlocks)."""
+
+    @staticmethod
+    def forward(ctx, x, res, cat):
+        x, res = _c(x), _c(res)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        xhat = torch.empty_like(x)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        if cat is None:
+            _lib.check(_lib.lib().as_layernorm_fwd(_lib.ptr(x), _lib.ptr(res), None, None, None, _lib.ptr(xhat), _lib.ptr(rstd), rows, D, 0,
+                                                   _lib.stream_ptr()), "as_layernorm_fwd")
+        else:
+            A_, per = cat
+            _lib.check(_lib.lib().as_layernorm_fwd_blockres(_lib.ptr(x), _lib.ptr(res), _lib.ptr(xhat), _lib.ptr(rstd), A_, rows // A_, per,
+                                                            D // per, _lib.stream_ptr()), "as_layernorm_fwd_blockres")
+        ctx.save_for_backward(xhat, rstd)
+        ctx.cat = cat
+        return xhat
+
+    @staticmethod
+    def backward(ctx, dxhat):
+        xhat, rstd = ctx.saved_tensors
+        D = xhat.shape[-1]
+        dxhat = _c(dxhat)
+        dx = torch.empty_like(xhat)
+        _lib.check(_lib.lib().as_layernorm_bwd(_lib.ptr(dxhat), _lib.ptr(xhat), _lib.ptr(rstd), None, _lib.ptr(dx), xhat.numel() // D, D,
+                                               _lib.stream_ptr()), "as_layernorm_bwd")
+        if ctx.cat is None:
+            return dx, dx, None
+        # the residual's gradient is the same tensor seen block-major: a strided [A, per, R, d] view, no copy (ChannelBlocks
+        # recognises it and reads the gradient in place)
+        A_, per = ctx.cat
+        return dx, dx.view(A_, xhat.shape[1], per, D // per).permute(0, 2, 1, 3), None
+
+
 class LayerNormAffine(torch.autograd.Function):
     """y = LayerNorm(x + res) * gamma + beta (res optional) -- the post-norm sites whose output is used directly."""
 
@@ -390,9 +430,10 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
             _gemm(A=kv, B=in_w, C=kv2, bias=in_b, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G, a_batch=Rs * d,
                   b_off=w_off[G:], c_batch=Rs * d, bias_off=bi_off[G:])
     att, att_saved, scale = attention_forward(q2, _c(kv2[0]), _c(kv2[1]), attn_mask, kpm, B, heads, training)
-    # out = q + out_proj(ctx): the residual is added by the GEMM's epilogue in the reference's order ((sum + bias) + q: as an
-    # initial accumulator value it would cost nothing, but the forward's rounding noise grows -- the full-width contours
-    # left the 1e-4 band, tests/test_gpu_transformer.py), the result goes straight into its final layout
+    # out-projection, straight into its final layout.  The residual `q + out` (:98) is NOT added here: every group's output
+    # goes into a LayerNorm only, which adds q as it reads (NormalizeRes / LayerNormAffine) -- no pass of its own, and the
+    # reference's order (sum + bias) + q.  (As the accumulators' initial value it costs the GEMM 110 us per 110-block launch
+    # and widens the forward's rounding noise: the full-width contours left the 1e-4 band; fetched by the GEMM's epilogue 450 us.)
     if cat is not None:
         A_, per = cat
         assert A_ * per == G
@@ -400,15 +441,17 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
         ldo = per * d
         c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
         lay = dict(c_off=c_off)
+        q_out = q.view(A_, per, R, d)
     else:
         out = new(G, R, d)
         ldo = d
         lay = dict(c_batch=R * d)
+        q_out = q
     _gemm(A=att, B=o_w, C=out, bias=o_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=ldo, batch=G, a_batch=R * d, b_batch=d * d,
-          bias_batch=d, res=q, res_ld=d, res_batch=R * d, precision=0, **lay)
+          bias_batch=d, **lay)
     if not training:
-        return out, None, None
-    return (out, (xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits, *att_saved),
+        return out, q_out, None, None
+    return (out, q_out, (xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits, *att_saved),
             (tgt, src, B, heads, cat, scale, ldo))
 
 
@@ -419,14 +462,16 @@ class ChannelBlocks(torch.autograd.Function):
 
         q = relu(LN(x_tgt) Wq^T + bq), k / v likewise from x_src      (the LayerNorm is shared: :70-76; its affine is folded
         q2, k2, v2 = in_proj(q, k, v); ctx = attention(q2, k2, v2)      into the three weights, x_* arrive normalised)
-        out = q + ctx Wo^T + bo                                        (the residual is the PROJECTED query, :98)
+        out = ctx Wo^T + bo ;  returns (out, q)                        (the residual `q + out`, :98, is added by the LayerNorm
+                                                                        that consumes the pair: NormalizeRes / LayerNormAffine)
 
     xt [Ct, R, d] / xs [Cs, Rs, d] are channel-major, block g reads channels tgt[g] / src[g].  cat = (A, per): the output
     is written as [A, R, per * d] -- block g = c * per + j lands in columns [j*d, (j+1)*d) of channel c, which is the
-    concatenation over the other channels that ChannelInteractionsLayer builds (:133-162) -- else block-major [G, R, d].
+    concatenation over the other channels that ChannelInteractionsLayer builds (:133-162), q then is [A, per, R, d] -- else
+    both are block-major [G, R, d].
 
-    What the fusion buys over one autograd node per Linear (measured): the residual is added by the
-    out-projection GEMM's epilogue; in the backward the residual's gradient starts the accumulators of the
+    What the fusion buys over one autograd node per Linear (measured): no pass for the residual add (it rides
+    in the next LayerNorm's read); in the backward the residual's gradient starts the accumulators of the
     in-projection's input-gradient GEMM, whose epilogue applies the ReLU masks from 1-bit images the forward GEMMs left
     (no pass over the [G, R, d] activations in between), the k and v
     sides run as one batch of 2G, the in-projection reads and writes the stacked [G, 3d, d] weight / gradient in place, and
@@ -435,15 +480,15 @@ class ChannelBlocks(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm, cfg):
         training = any(ctx.needs_input_grad)
-        out, saved, meta = channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm,
-                                                  cfg, training)
+        out, q_out, saved, meta = channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask,
+                                                         kpm, cfg, training)
         if training:
             ctx.save_for_backward(*saved)
             ctx.meta = meta
-        return out
+        return out, q_out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dq_res):
         saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
         xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits = saved[:15]
         att_saved = saved[15:]
@@ -460,9 +505,20 @@ class ChannelBlocks(torch.autograd.Function):
         if cat is not None:
             A_, per = cat
             c_off = _table(dev, ("cat", A_, per, R, d), lambda: [c * R * per * d + j * d for c in range(A_) for j in range(per)])
-            a_lay, r_lay = dict(a_off=c_off), dict(res_off=c_off)
+            a_lay = dict(a_off=c_off)
+            in_place = (A_, per, R, d), (R * per * d, d, per * d, 1)
         else:
-            a_lay, r_lay = dict(a_batch=R * d), dict(res_batch=R * d)
+            a_lay = dict(a_batch=R * d)
+            in_place = (G, R, d), (R * d, d, 1)
+        # the gradient over the residual (q is the group's second output): normally the consuming LayerNorm's dx seen in q's
+        # layout, i.e. `dout`'s own storage -- read in place as the initial value of the query gradient's accumulators
+        if dq_res is None:
+            r_lay = {}
+        elif dq_res.data_ptr() == dout.data_ptr() and (tuple(dq_res.shape), tuple(dq_res.stride())) == in_place:
+            r_lay = dict(res=dout, res_ld=ldo, res_off=c_off) if cat is not None else dict(res=dout, res_ld=d, res_batch=R * d)
+        else:
+            dq_res = dq_res.contiguous().view(G, R, d)
+            r_lay = dict(res=dq_res, res_ld=d, res_batch=R * d)
         same = R == Rs
         # ---- out-projection: d ctx = dout Wo ; dWo = dout^T ctx (+ its bias gradient as the column sums of dout)
         datt = new(G, R, d)
@@ -485,7 +541,7 @@ class ChannelBlocks(torch.autograd.Function):
         dq, dkv = new(G, R, d), new(2, G, Rs, d)
         w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
         _gemm(A=dq2, B=in_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=3 * d * d,
-              c_batch=R * d, res=dout, res_ld=ldo, res_init=1, mask_bits=qbits, mask_batch=R * ncb, precision=0, **r_lay)
+              c_batch=R * d, mask_bits=qbits, mask_batch=R * ncb, precision=0, **r_lay)
         _gemm(A=dkv2, B=in_w, C=dkv, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d, b_off=w_off[G:],
               c_batch=Rs * d, mask_bits=kvbits, mask_batch=Rs * ncb, precision=0)
         del dp2, dq2, dkv2

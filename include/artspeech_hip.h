@@ -320,6 +320,14 @@ int as_area_function_fwd(const double* internal_wall, const double* external_wal
 int as_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xhat,
                      float* rstd, int64_t rows, int32_t D, int64_t group_rows, void* stream);
 
+/* Affine-free LayerNorm of x + res where x [channels][rows][per * block] is the concatenation of `per` blocks per channel and
+ * res [channels * per][rows][block] is block-major:  xhat[c][r][j*block + f] = LN_row(x[c][r][:] + res[c*per + j][r][f]).
+ * This is `LayerNorm(cat_j(q_j + out_proj_j(ctx_j)))` of ChannelInteractionsLayer (transformer/models.py:98, 133-162) with x the
+ * out-projections written into the concatenated layout and res the projected queries where the blocks left them: the
+ * residual add costs no pass of its own and keeps the reference's order, (sum + bias) + q.  rstd [channels * rows] optional. */
+int as_layernorm_fwd_blockres(const float* x, const float* res, float* xhat, float* rstd, int32_t channels, int64_t rows,
+                              int32_t per, int32_t block, void* stream);
+
 /* Fold a LayerNorm affine into the following Linear for `heads` independent (W [R][K], gamma/beta [K], b [R])
  * sets: Wf = W.diag(gamma), bf = b + W.beta (then Linear(LN(x)) == x_hat . Wf^T + bf). */
 int as_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int32_t heads,

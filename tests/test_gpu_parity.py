@@ -201,25 +201,30 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
         _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
         torch.cuda.synchronize()
 
-    # (1) out[c, :, j*d:(j+1)*d] = q[g] + ctx[g] w[g]^T + b[g], g = c * per + j: concatenated layout through c_off / ldc
+    # (1) out[c, :, j*d:(j+1)*d] = q[g] + ctx[g] w[g]^T + b[g], g = c * per + j: concatenated layout through c_off / ldc, the
+    # residual as the accumulators' initial value
     t_ctx, t_w, t_b, t_q = T_(ctx, dev), T_(w, dev), T_(b, dev), T_(q, dev)
     out = torch.full((A_, R, per * d), float("nan"), device=dev)
     coff = tbl([c * R * per * d + j * d for c in range(A_) for j in range(per)])
+    call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
+         bias_batch=d, c_off=coff, res=t_q, res_ld=d, res_batch=R * d)
     ref = q + np.einsum("grk,gnk->grn", ctx.astype(np.float64), w) + b[:, None]
     ref_cat = ref.reshape(A_, per, R, d).transpose(0, 2, 1, 3).reshape(A_, R, per * d)
-    for res_init in (0, 1):   # added by the epilogue (reference order) / initial value of the accumulators
-        out.fill_(float("nan"))
-        call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
-             bias_batch=d, c_off=coff, res=t_q, res_ld=d, res_batch=R * d, res_init=res_init)
-        assert_close(out.cpu().numpy(), ref_cat, rtol=2e-5, atol=2e-5 * np.sqrt(d), what=f"out-projection + residual ({res_init}), concatenated")
-    if not big:   # the late residual reproduces (sum + bias) + res bit for bit: the plain kernel's result + a float add
-        plain = torch.empty((G, R, d), device=dev)
-        call(A=t_ctx, B=t_w, C=plain, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d, b_batch=d * d,
-             bias_batch=d, c_batch=R * d)
-        late = torch.empty((G, R, d), device=dev)
-        call(A=t_ctx, B=t_w, C=late, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_batch=R * d, b_batch=d * d,
-             bias_batch=d, c_batch=R * d, res=t_q, res_ld=d, res_batch=R * d)
-        assert torch.equal(late, plain + t_q)
+    assert_close(out.cpu().numpy(), ref_cat, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="out-projection + residual, concatenated")
+
+    # (1b) the forward's form: plain out-projection into the concatenated layout, the residual added by the LayerNorm that
+    # reads it (as_layernorm_fwd_blockres): x_hat = LN(cat_j(out_j + q_j))
+    from artspeech_amd import _lib as _l
+    call(A=t_ctx, B=t_w, C=out, bias=t_b, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=per * d, batch=G, a_batch=R * d, b_batch=d * d,
+         bias_batch=d, c_off=coff)
+    xhat = torch.full_like(out, float("nan"))
+    rstd = torch.empty(A_ * R, device=dev)
+    _l.check(L.as_layernorm_fwd_blockres(_l.ptr(out), _l.ptr(t_q), _l.ptr(xhat), _l.ptr(rstd), A_, R, per, d, _l.stream_ptr()),
+             "as_layernorm_fwd_blockres")
+    mu = ref_cat.mean(-1, keepdims=True)
+    var = ((ref_cat - mu) ** 2).mean(-1, keepdims=True)
+    assert_close(xhat.cpu().numpy(), (ref_cat - mu) / np.sqrt(var + 1e-5), rtol=2e-5, atol=2e-5, what="LayerNorm of out + block-major residual")
+    assert_close(rstd.cpu().numpy().reshape(A_, R, 1), 1 / np.sqrt(var + 1e-5), rtol=2e-5, atol=0, what="rstd")
 
     # (2) the ReLU's bit image from a forward GEMM: bit n % 32 of word n / 32 of a row = (result > 0)
     xin = rng.randn(G, R, d).astype(np.float32)
@@ -245,7 +250,7 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
     t_dq2, t_dcat = T_(dq2, dev), T_(dcat, dev)
     dq = torch.full((G, R, d), float("nan"), device=dev)
     call(A=t_dq2, B=t_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=d * d, c_batch=R * d,
-         res=t_dcat, res_ld=per * d, res_off=coff, res_init=1, mask_bits=bits, mask_batch=R * ncb)
+         res=t_dcat, res_ld=per * d, res_off=coff, mask_bits=bits, mask_batch=R * ncb)
     dres = dcat.reshape(A_, R, per, d).transpose(0, 2, 1, 3).reshape(G, R, d)
     ref = (np.einsum("grn,gnk->grk", dq2.astype(np.float64), w) + dres) * (yh > 0)
     assert_close(dq.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(d), what="input gradient + residual gradient, masked")

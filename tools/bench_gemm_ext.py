@@ -42,17 +42,17 @@ nt = dict(M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, batch=G, a_batch=R * d, b_b
 nn = dict(M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, batch=G, a_batch=R * d, b_batch=d * d)
 cases = {
     "forward, bias + relu (plain)": (lambda: gemm(A=x, B=w, C=out, bias=b, bias_batch=d, act=1, ldc=d, c_batch=R * d, **nt), G),
+    "forward, bias -> concatenated (plain)": (lambda: gemm(A=x, B=w, C=cat, bias=b, bias_batch=d, ldc=per * d, c_off=coff, **nt), G),
     "forward, bias (plain) + torch add": (lambda: (gemm(A=x, B=w, C=out, bias=b, bias_batch=d, ldc=d, c_batch=R * d, **nt), out.add_(y)), G),
-    "forward, bias + residual (ext)": (lambda: gemm(A=x, B=w, C=out, bias=b, bias_batch=d, ldc=d, c_batch=R * d, res=y, res_ld=d, res_batch=R * d, **nt), G),
-    "forward, bias + residual as accumulator start (ext)": (lambda: gemm(A=x, B=w, C=out, bias=b, bias_batch=d, ldc=d, c_batch=R * d, res=y, res_ld=d,
-                                                                         res_batch=R * d, res_init=1, **nt), G),
-    "forward, bias + residual -> concatenated (ext)": (lambda: gemm(A=x, B=w, C=cat, bias=b, bias_batch=d, ldc=per * d, c_off=coff, res=y, res_ld=d, res_batch=R * d, **nt), G),
+    "forward, bias + residual as the accumulators' start (ext)": (lambda: gemm(A=x, B=w, C=out, bias=b, bias_batch=d, ldc=d, c_batch=R * d, res=y,
+                                                                                res_ld=d, res_batch=R * d, **nt), G),
+    "forward, bias + residual start -> concatenated (ext)": (lambda: gemm(A=x, B=w, C=cat, bias=b, bias_batch=d, ldc=per * d, c_off=coff, res=y, res_ld=d, res_batch=R * d, **nt), G),
     "input gradient (plain)": (lambda: gemm(A=x, B=w, C=out, ldc=d, c_batch=R * d, **nn), G),
     "forward, bias + relu + bit image (ext)": (lambda: gemm(A=x, B=w, C=out, bias=b, bias_batch=d, act=1, ldc=d, c_batch=R * d, relu_bits=bits,
                                                             relu_bits_batch=R * (d // 32), **nt), G),
     "input gradient + relu mask (ext)": (lambda: gemm(A=x, B=w, C=out, ldc=d, c_batch=R * d, mask_bits=bits, mask_batch=R * (d // 32), **nn), G),
     "input gradient + residual + relu mask (ext)": (lambda: gemm(A=x, B=w, C=out, ldc=d, c_batch=R * d, mask_bits=bits, mask_batch=R * (d // 32),
-                                                                    res=cat, res_ld=per * d, res_off=coff, res_init=1, **nn), G),
+                                                                    res=cat, res_ld=per * d, res_off=coff, **nn), G),
     "channel sums, segmented K = 10 d (ext)": (lambda: gemm(A=x, B=w, C=dx, M=R, N=d, K=per * d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=A_,
                                                               c_batch=R * d, k_seg=d, a_seg_off=aseg, b_seg_off=bseg), G),
 }
