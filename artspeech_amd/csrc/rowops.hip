@@ -551,12 +551,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
 // ---- LayerNorm with optional residual input and grouped affine ------------------------------------
 // one wave per row, NW = ceil(D / 64) values per lane (template: rows are 20 .. 2816 wide in the models); branch-free
 // clamped loads so that all of a lane's loads are in flight together.
-template <int NW>
+template <int NW, bool AFFINE>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ xhat,
                                                             float* __restrict__ rstd, long rows, int D, long group_rows,
-                                                            float eps, int res_block = 0, long res_rows = 0) {
+                                                            float eps, int res_block, long res_rows) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -567,14 +567,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long res_jstride = res_block > 0 ? res_rows * res_block - res_block : 0;   // block j's row starts j * res_rows * res_block further
     // group_rows > 0: consecutive blocks of rows share a parameter set; < 0: parameter set = row % (-group_rows)
     const long g = group_rows > 0 ? row / group_rows : (group_rows < 0 ? row % (-group_rows) : 0);
-    float v[NW], ga[NW], be[NW];
+    float v[NW], ga[AFFINE ? NW : 1], be[AFFINE ? NW : 1];   // (affine-free: no registers for the parameters)
 #pragma unroll
     for (int c = 0; c < NW; ++c) {
         const int i = lane + 64 * c;
         const int ic = i < D ? i : D - 1;
-        v[c] = rr ? xr[ic] + rr[ic + (res_block > 0 ? (ic / res_block) * res_jstride : 0)] : xr[ic];
-        ga[c] = gamma ? gamma[g * D + ic] : 1.f;
-        be[c] = gamma ? beta[g * D + ic] : 0.f;
+        long ro = ic;
+        if (res_block > 0) {
+            // block index of feature ic = lane + 64 c: wave-uniform c / (res_block / 64) when the blocks are whole multiples of the wave
+            // (lanes beyond the row re-read its last feature: clamp the block index with them)
+            const int j = res_block % 64 == 0 ? min(64 * c, D - 64) / res_block : ic / res_block;
+            ro += j * res_jstride;
+        }
+        v[c] = rr ? xr[ic] + rr[ro] : xr[ic];
+        if (AFFINE) {
+            ga[c] = gamma[g * D + ic];
+            be[c] = beta[g * D + ic];
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         if (i < D) {
             const float xh = v[c] * rs;
             if (xhat) xhat[row * D + i] = xh;
-            if (y) y[row * D + i] = xh * ga[c] + be[c];
+            if (y) y[row * D + i] = AFFINE ? xh * ga[c] + be[c] : xh;
         }
     }
     if (rstd && lane == 0) rstd[row] = rs;
@@ -864,9 +873,15 @@ extern "C" int as_layernorm_fwd(const float* x, const float* res, const float* g
                                 float* rstd, int64_t rows, int32_t D, int64_t group_rows, void* stream) {
     AS_REQUIRE(x && (y || xhat) && rows > 0 && D > 0 && (!gamma == !beta), AS_ERR_BAD_ARG, "as_layernorm_fwd: bad argument");
     AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd: row length %d > %d", D, 64 * 44);
-#define AS_LN_FWD(NW)                                                                                                          \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<NW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, \
-                       xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f)
+#define AS_LN_FWD(NW)                                                                                                                  \
+    do {                                                                                                                               \
+        if (gamma)                                                                                                                     \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<NW, true>), dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,  \
+                               beta, y, xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f, 0, 0L);                                         \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, \
+                               beta, y, xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f, 0, 0L);                                         \
+    } while (0)
     if (D <= 64) AS_LN_FWD(1);
     else if (D <= 128) AS_LN_FWD(2);
     else if (D <= 256) AS_LN_FWD(4);
@@ -885,8 +900,8 @@ extern "C" int as_layernorm_fwd_blockres(const float* x, const float* res, float
     AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd_blockres: row length %d > %d", D, 64 * 44);
     const long total = (long)channels * rows;
 #define AS_LN_FWD(NW)                                                                                                              \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<NW>, dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res, (const float*)nullptr, \
-                       (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block, (long)rows)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false>), dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res,         \
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block, (long)rows)
     if (D <= 64) AS_LN_FWD(1);
     else if (D <= 128) AS_LN_FWD(2);
     else if (D <= 256) AS_LN_FWD(4);

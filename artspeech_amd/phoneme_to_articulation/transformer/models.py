@@ -329,7 +329,7 @@ class ArtSpeechTransformer(nn.Module):
         if kv is None:
             return ChannelBlocks.apply(xhat_tgt, xhat_src, P[n + "q_w"], P[n + "q_b"], P[n + "k_w"], P[n + "k_b"], P[n + "v_w"],
                                        P[n + "v_b"], P[n + "in_w"], P[n + "in_b"], P[n + "o_w"], P[n + "o_b"], P[n + "ln_w"],
-                                       P[n + "ln_b"], attn_mask, kpm, (tgt_idx, src_idx, B, self.num_heads, cat))
+                                       P[n + "ln_b"], attn_mask, kpm, (tgt_idx, src_idx, B, self.num_heads, cat, torch.is_grad_enabled()))
         # generate(): the memory side (k2, v2) was projected once per call (_memory_kv); inference only, same arithmetic
         assert not torch.is_grad_enabled()
         return channel_blocks_forward(xhat_tgt, None, P[n + "q_w"], P[n + "q_b"], None, None, None, None, P[n + "in_w"], P[n + "in_b"],

@@ -479,7 +479,11 @@ class ChannelBlocks(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask, kpm, cfg):
-        training = any(ctx.needs_input_grad)
+        # cfg[5]: the caller's torch.is_grad_enabled() -- inside forward() autograd is always off, and the parameters keep
+        # requires_grad under no_grad(), so needs_input_grad alone cannot tell an inference pass (which then would write the
+        # attention probabilities and the ReLU bit images for nothing)
+        training = bool(cfg[5]) and any(ctx.needs_input_grad)
+        cfg = cfg[:5]
         out, q_out, saved, meta = channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w, o_b, ln_w, ln_b, attn_mask,
                                                          kpm, cfg, training)
         if training:
