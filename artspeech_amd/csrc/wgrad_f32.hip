@@ -60,6 +60,7 @@ struct WgradK {
     long item0, red0;
     float* colsum_b; long colsum_b_batch; float* csb_slab;
     int c_trans;
+    long tile0;   // stream-K launches: first output tile of this problem in the launch's tile numbering
 #ifdef AS_DIAG
     int abl;  // diagnostic ablation (AS_WGRAD_ABL=1): no global loads after the first two k-tiles (matrix work only)
 #else
@@ -81,13 +82,25 @@ __device__ __forceinline__ void glds16(const float* src, float* dst) {
 
 // BK = 32: one workgroup per CU (144 KB of LDS at BN = 256, two k-tiles = 96 KB in flight).  BK = 16: 72 KB, two workgroups
 // per CU -- the partner's MFMAs cover this one's barriers, prologue and epilogue.
+// Stream-K (streamk = 1): the launch's work is the flat sequence of k-tiles (32 frames) of all its output tiles, tile after
+// tile; workgroup w takes units [w U, (w + 1) U).  A tile that one workgroup covers from its first k-tile to its last is
+// written as usual; a tile cut by a workgroup boundary leaves one PIECE per workgroup in the slab (slot 0: the piece a
+// workgroup starts with in the middle of a tile, slot 1: a piece that starts a tile and stops short of its end) and
+// wgrad_reduce_sk_kernel adds a tile's pieces in k order (deterministic).  Every CU works for the same time whatever the
+// tile count is (220 tiles of a 110-block transformer group leave 36 of 256 CUs idle for the whole launch otherwise), and
+// the slab holds at most two pieces per workgroup instead of a split factor times the whole result.
+constexpr int PIECE_FLOATS = BM * 256 + BM + 256;   // tile + column sums of the A and of the B operand
 struct WgradMulti {
     int n, per_xcd;
     long total_items, total_red;
+    int streamk, nkt;           // nkt = K / 32, the same for every problem of a stream-K launch
+    long unit_per_wg, total_units, total_tiles;
+    float* pieces;              // [workgroups][2][PIECE_FLOATS]
     WgradK p[MAXP];
 };
 
-template <int BN, int BK>
+// SK: the stream-K instantiation (mm.streamk launches); the plain one compiles to a single pass of the segment loop.
+template <int BN, int BK, bool SK = false>
 __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMulti mm) {
     constexpr int WN = BN / 4, TN = WN / 32, TM = 2;   // 2 x 4 waves; a wave owns 64 rows x WN columns
     constexpr int TILE = BK * (BM + BN);                // floats per ring slot: A image [BK][BM] then B image [BK][BN]
@@ -104,21 +117,41 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
     // equal shares whatever the counts are.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     if (slot >= mm.per_xcd) return;
-    long item = (long)xcd * mm.per_xcd + slot;
-    if (item >= mm.total_items) return;
+    const long wg = (long)xcd * mm.per_xcd + slot;
+    if (wg >= mm.total_items) return;
+    // stream-K: this workgroup's k-tile units [u, u_end) of the flat (tile, k-tile) sequence, one SEGMENT (the part inside one
+    // output tile) per pass of the loop below; otherwise one pass for the work item `wg`
+    long u = SK ? wg * mm.unit_per_wg : 0;
+    const long u_end = SK ? min(u + mm.unit_per_wg, mm.total_units) : 1;
+  for (bool first_seg = true; u < u_end; first_seg = false) {
+    long item = wg;
+    int kt0 = 0, kt1 = 0;
+    if (SK) {
+        item = u / mm.nkt;
+        kt0 = (int)(u - item * mm.nkt);
+        kt1 = (int)min((long)mm.nkt, kt0 + (u_end - u));
+        u += kt1 - kt0;
+    } else {
+        u = u_end;
+    }
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
-        if (i < mm.n && item >= mm.p[i].item0) pi = i;
+        if (i < mm.n && item >= (SK ? mm.p[i].tile0 : mm.p[i].item0)) pi = i;
     const WgradK& g = mm.p[pi];
-    item -= g.item0;
+    item -= SK ? g.tile0 : g.item0;
     const int tm = (int)(item % g.tiles_m);
     const long combo = item / g.tiles_m;
     const int tn = (int)(combo % g.tiles_n);
     const long rest = combo / g.tiles_n;
-    const int ks = (int)(rest % g.splitk), bz = (int)(rest / g.splitk);
+    const int ks = (int)(rest % g.splitk), bz = (int)(rest / g.splitk);   // (stream-K problems have splitk == 1)
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);   // both multiples of BK (host contract)
+    const int kbeg = SK ? kt0 * BK : ks * g.kchunk;
+    const int kend = SK ? kt1 * BK : min(g.K, kbeg + g.kchunk);   // both multiples of BK (host contract)
+    // a piece: part of a tile's reduction only -> the slab, summed by wgrad_reduce_sk_kernel
+    const bool piece = SK && !(kt0 == 0 && kt1 == mm.nkt);
+    float* const piece_out = SK ? mm.pieces + (wg * 2 + (kt0 > 0 ? 0 : 1)) * PIECE_FLOATS : nullptr;
+    if (SK && !first_seg) __syncthreads();   // the previous segment's epilogue may still be reading the LDS the DMAs below overwrite
     const float* __restrict__ A = g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch);
     const float* __restrict__ B = g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch);
 
@@ -237,9 +270,10 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
     if (do_cs) {
         smem[tid] = cs;   // every fragment read and every DMA is behind the loop's last barrier
         __syncthreads();
-        if (tid < BM && m0 + tid < g.M) {
+        if (tid < BM && (piece || m0 + tid < g.M)) {
             const float s = ((smem[tid] + smem[BM + tid]) + smem[2 * BM + tid]) + smem[3 * BM + tid];
-            if (g.splitk > 1) g.cs_slab[((long)ks * g.batch + bz) * g.M + m0 + tid] = s;
+            if (piece) piece_out[BM * 256 + tid] = s;
+            else if (g.splitk > 1) g.cs_slab[((long)ks * g.batch + bz) * g.M + m0 + tid] = s;
             else g.colsum[(long)bz * g.colsum_batch + m0 + tid] = s;
         }
     }
@@ -247,16 +281,27 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
         __syncthreads();   // (the A-side exchange above may still be reading)
         smem[tid] = csb;
         __syncthreads();
-        if (tid < BN && n0 + tid < g.N) {
+        if (tid < BN && (piece || n0 + tid < g.N)) {
             float s = smem[tid];
 #pragma unroll
             for (int q = 1; q < NT / BN; ++q) s += smem[q * BN + tid];
-            if (g.splitk > 1) g.csb_slab[((long)ks * g.batch + bz) * g.N + n0 + tid] = s;
+            if (piece) piece_out[BM * 256 + BM + tid] = s;
+            else if (g.splitk > 1) g.csb_slab[((long)ks * g.batch + bz) * g.N + n0 + tid] = s;
             else g.colsum_b[(long)bz * g.colsum_b_batch + n0 + tid] = s;
         }
     }
 
     // ---- epilogue: D[i][j], j = lane & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (piece) {   // the whole [BM][BN] tile, dense (rows / columns beyond M / N hold finite don't-cares the reduce never reads)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    piece_out[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WN + j * 32 + l31] = acc[i][j][r];
+        continue;
+    }
     float* out;
     long ld;
     if (g.splitk > 1) {
@@ -281,6 +326,65 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
                 *c = acc_c ? *c + acc[i][j][r] : acc[i][j][r];
             }
     }
+  }   // segments
+}
+
+// Stream-K: adds the pieces of every output tile that a workgroup boundary cut, in k order, and stores the tile like the
+// main kernel would have (transposed / accumulating / column sums).  One thread per float4 of a tile + one per column sum.
+template <int BN>
+__global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(WgradMulti mm) {
+    constexpr int PER_TILE = BM * BN / 4 + BM + BN;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tile = idx / PER_TILE;
+    if (tile >= mm.total_tiles) return;
+    const int e = (int)(idx - tile * PER_TILE);
+    const long ub = tile * mm.nkt, ue = ub + mm.nkt;
+    const long w_first = ub / mm.unit_per_wg, w_last = (ue - 1) / mm.unit_per_wg;
+    if (w_first == w_last) return;   // one workgroup had the whole tile and stored it
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < mm.n && tile >= mm.p[i].tile0) pi = i;
+    const WgradK& g = mm.p[pi];
+    const long item = tile - g.tile0;
+    const int tm = (int)(item % g.tiles_m);
+    const long combo = item / g.tiles_m;
+    const int tn = (int)(combo % g.tiles_n);
+    const long bz = combo / g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // piece of workgroup w for this tile: slot 0 if w starts inside the tile, slot 1 if the tile starts inside w
+    auto piece_of = [&](long w) { return mm.pieces + (w * 2 + (w * mm.unit_per_wg > ub ? 0 : 1)) * PIECE_FLOATS; };
+    if (e < BM * BN / 4) {
+        const int row = e / (BN / 4), c4 = e - row * (BN / 4);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long w = w_first; w <= w_last; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(piece_of(w) + row * BN + c4 * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int gr = m0 + row, gc = n0 + c4 * 4;
+        if (gr >= g.M || gc >= g.N) return;      // (N is a multiple of 4: a float4 is wholly inside or outside)
+        float* cb = g.C + (g.c_off ? g.c_off[bz] : bz * g.c_batch);
+        const float v4[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* c = g.c_trans ? cb + (long)(gc + q) * g.ldc + gr : cb + (long)gr * g.ldc + gc + q;
+            *c = g.accumulate ? *c + v4[q] : v4[q];
+        }
+        return;
+    }
+    const int ce = e - BM * BN / 4;
+    if (ce < BM) {                                // column sums of A (bias gradient): the tiles of the first column block hold them
+        if (g.colsum == nullptr || tn != 0 || m0 + ce >= g.M) return;
+        float s = 0.f;
+        for (long w = w_first; w <= w_last; ++w) s += piece_of(w)[BM * 256 + ce];
+        g.colsum[bz * g.colsum_batch + m0 + ce] = s;
+        return;
+    }
+    const int cn = ce - BM;
+    if (g.colsum_b == nullptr || tm != 0 || n0 + cn >= g.N) return;
+    float s = 0.f;
+    for (long w = w_first; w <= w_last; ++w) s += piece_of(w)[BM * 256 + BM + cn];
+    g.colsum_b[bz * g.colsum_b_batch + n0 + cn] = s;
 }
 
 // C (+)= sum over the k-slabs in slab order, every problem of the launch in one grid: per problem first the float4 groups
@@ -373,9 +477,17 @@ bool describe(const as_gemm* g, WgradK& k) {
 template <int BNT>
 int launch_multi(WgradMulti& mm, int bk, hipStream_t st) {
     const dim3 grid((unsigned)(8 * mm.per_xcd));
-    if (bk == 16) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 16>), grid, dim3(NT), 0, st, mm);
+    if (mm.streamk) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true>), grid, dim3(NT), 0, st, mm);
+    else if (bk == 16) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 16>), grid, dim3(NT), 0, st, mm);
     else hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32>), grid, dim3(NT), 0, st, mm);
     AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
+    if (mm.streamk) {
+        constexpr long PER_TILE = BM * BNT / 4 + BM + BNT;
+        const long threads = mm.total_tiles * PER_TILE;
+        hipLaunchKernelGGL((wgrad_reduce_sk_kernel<BNT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, mm);
+        AS_LAUNCH_CHECK("as_gemm_f32(wgrad stream-K reduce)");
+        return 0;
+    }
     bool any = false;
     for (int i = 0; i < mm.n; ++i) any = any || mm.p[i].splitk > 1;
     if (any) {
@@ -430,6 +542,25 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
         if (S > g->K / 128) S = g->K / 128;
         if (S * (per + per_cs) > g->splitk_ws_floats) S = g->splitk_ws_floats / (per + per_cs);
         if (S < 1) S = 1;
+    }
+    // Many tiles that do not fill whole rounds of the CUs: stream-K (see WgradMulti) instead of whole tiles per workgroup
+    static const bool no_sk = AS_DIAG_SET("AS_WGRAD_NO_STREAMK");
+    const long rounds = (tiles + cus - 1) / cus;
+    if (!no_sk && bk == 32 && g->splitk_ws && tiles * 2 >= cus && tiles * 100 < rounds * cus * 95 && g->K / 32 >= 16 &&
+        (long)cus * 2 * PIECE_FLOATS <= g->splitk_ws_floats) {
+        k.kchunk = g->K; k.splitk = 1; k.tile0 = 0;
+        k.ncombos = (long)g->batch * k.tiles_n;
+        mm.n = 1;
+        mm.streamk = 1;
+        mm.nkt = g->K / 32;
+        mm.total_tiles = tiles;
+        mm.total_units = tiles * mm.nkt;
+        mm.unit_per_wg = (mm.total_units + cus - 1) / cus;
+        mm.total_items = (mm.total_units + mm.unit_per_wg - 1) / mm.unit_per_wg;   // workgroups
+        mm.per_xcd = (int)((mm.total_items + 7) / 8);
+        mm.pieces = g->splitk_ws;
+        const int rc = bn == 256 ? launch_multi<256>(mm, bk, st) : launch_multi<128>(mm, bk, st);
+        return rc == 0 ? 1 : rc;
     }
     k.kchunk = (int)as_round_up(as_cdiv(g->K, S), KALIGN);
     k.splitk = as_cdiv(g->K, k.kchunk);

@@ -53,7 +53,7 @@ def _table32(dev, key, build):
 
 def _slab(dev):
     if dev not in _SLAB:
-        _SLAB[dev] = torch.empty(8 << 20, dtype=torch.float32, device=dev)  # split-K partial tiles (32 MB)
+        _SLAB[dev] = torch.empty(20 << 20, dtype=torch.float32, device=dev)  # split-K slabs / stream-K pieces (80 MB)
     return _SLAB[dev]
 
 
