@@ -265,36 +265,63 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
         // uniform row pointer + one of two per-lane 32-bit offsets (as in the forward: per-element 64-bit addresses would be
         // hoisted out of the strip loop, two VGPRs each).  Rows are clamped on the uniform side, so every load is in bounds.
         const int off0 = qc, off4 = qc + 4 * lh * a.T;
+        // the probabilities of block blk + 1 go in flight BEFORE the matrix work of block blk: a block's loads queue behind the
+        // previous block's stores (vector memory operations retire in order), so one block of look-ahead is what lets a
+        // wave's memory pipe work while its 32 MFMAs run (before: load -> MFMAs -> store, block after block: 2.2 ms per
+        // 110-block group for 4.5 GB = 2 TB/s)
+        auto fetch = [&](int blk, float (&pv)[16]) {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            float pv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {  // the block's probabilities go in flight ahead of its MFMAs
-                const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < 16; ++r) {
+                int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                // (recomputed per use on the scalar unit: hoisted out of the strip loop, the 2 x 16 NB row pointers are
+                // ~450 SGPRs that end up in VGPR lanes and scratch)
+                asm volatile("" : "+s"(ku));
                 const float* row = pz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
                 pv[r] = row[ku + 4 < a.Tk ? off4 : off0];
             }
+        };
+        auto block = [&](int blk, const float (&pv)[16]) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            float vr[HS];
             const float* vrow = Vs + (blk * 32 + l31) * LD + lh * HS;
+            constexpr int VC = HS < 8 ? HS : 8;   // the V row in chunks of 8 reduction steps: 8 live registers instead of HS
 #pragma unroll
-            for (int s = 0; s < HS; s += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(vrow + s);
-                vr[s] = t.x; vr[s + 1] = t.y; vr[s + 2] = t.z; vr[s + 3] = t.w;
+            for (int s0 = 0; s0 < HS; s0 += VC) {
+                float vr[VC];
+#pragma unroll
+                for (int s = 0; s < VC; s += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(vrow + s0 + s);
+                    vr[s] = t.x; vr[s + 1] = t.y; vr[s + 2] = t.z; vr[s + 3] = t.w;
+                }
+#pragma unroll
+                for (int s = 0; s < VC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[s], gv[s0 + s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int s = 0; s < HS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[s], gv[s], acc, 0, 0, 0);
-#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                asm volatile("" : "+s"(ku));
                 const bool both = ku + 4 < a.Tk;                    // uniform: rows ku and ku + 4 both exist
                 const bool mine = both || (lh == 0 && ku < a.Tk);   // this half-wave's key row exists
                 float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
                 if (mine && q < a.T) row[both ? off4 : off0] = pv[r] * (acc[r] - D) * a.scale;
             }
+        };
+        float pv0[16], pv1[16];
+        fetch(0, pv0);
+#pragma unroll
+        for (int blk = 0; blk < NB; blk += 2) {
+            if (blk + 1 < NB) fetch(blk + 1, pv1);
             __builtin_amdgcn_sched_barrier(0);
+            block(blk, pv0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (blk + 1 < NB) {
+                if (blk + 2 < NB) fetch(blk + 2, pv0);
+                __builtin_amdgcn_sched_barrier(0);
+                block(blk + 1, pv1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
