@@ -508,6 +508,50 @@ __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
     // the next row's target loads are in flight while this row's stores go out
     float part = 0.f;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    if (Np <= 64) {
+        // a lane owns one point of each of the wave's (up to 8) frames.  ALL target coordinates are requested before the first
+        // store goes out: vector memory operations retire in order, so a target load issued behind a frame's stores waits
+        // for their acknowledgement -- frame after frame, that chain was most of this epilogue
+        float tx[8], ty[8];
+        bool in[8], valid[8];
+        const int nl = min(lane, Np - 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = wave_u + 8 * k;
+            const int frame = m0 + r;
+            in[k] = r < rows && frame < g.M;
+            const int fc = in[k] ? frame : m0;
+            const int b = fc / g.T, t = fc - b * g.T;
+            valid[k] = in[k] && t < g.lengths[b];
+            const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
+            tx[k] = tg[nl];
+            ty[k] = tg[Np + nl];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!in[k]) continue;                       // wave-uniform
+            const int r = wave_u + 8 * k;
+            const long frame = m0 + r;
+            float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
+            float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
+            if (lane < Np) {
+                const float ox = smem[r * ON + lane], oy = smem[r * ON + Np + lane];
+                o[lane] = ox;
+                o[Np + lane] = oy;
+                float gx = 0.f, gy = 0.f;
+                if (valid[k]) {
+                    const float dx = ox - tx[k], dy = oy - ty[k];
+                    const float d = sqrtf(dx * dx + dy * dy);
+                    part += d;
+                    const float gg = g.scale / d;                   // NaN at zero distance, as torch autograd
+                    gx = dx * gg * ox * (1.f - ox);                  // through the sigmoid (same product order as the unfused kernels)
+                    gy = dy * gg * oy * (1.f - oy);
+                }
+                dz[lane] = gx;
+                dz[Np + lane] = gy;
+            }
+        }
+    } else
     for (int r = wave_u; r < rows; r += 8) {
         const int frame = m0 + r;
         if (frame >= g.M) break;
