@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restr
 
 // ---- dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) * (relu_src > 0) ------------------------
 // dy and dx may alias (in-place): a lane reads all its elements before it writes any.
-template <int MW>
+// MASKED = false: no ReLU mask operand (no registers for it: 88 instead of 132 live values per lane at MW = 44, one wave per
+// SIMD became three)
+// WHOLE: D is a multiple of 64, so a lane's element c is either in the row for the whole wave or for none of it: the index
+// is lane + (a wave-uniform 64 c or 0) -- ONE address VGPR for all the loads instead of a clamped index per element
+template <int MW, bool MASKED, bool WHOLE>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ relu_src, float* dx,
@@ -71,16 +75,16 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
     if (row >= rows) return;
     const float* dyr = dy + row * D;
     const float* xr = xhat + row * D;
-    float g[MW], h[MW], m[MW];
+    float g[MW], h[MW], m[MASKED ? MW : 1];
 #pragma unroll
     for (int c = 0; c < MW; ++c) {  // branch-free clamped loads: everything in flight together
         const int i = lane + 64 * c;
-        const int ic = i < D ? i : D - 1;
+        const int ic = WHOLE ? lane + (64 * c < D ? 64 * c : 0) : (i < D ? i : D - 1);
         g[c] = dyr[ic];
         h[c] = xr[ic];
-        m[c] = 1.f;
+        if (MASKED) m[c] = 1.f;
     }
-    if (relu_src) {  // (one uniform branch around the whole batch, not one per element)
+    if (MASKED && relu_src) {  // (one uniform branch around the whole batch, not one per element)
         const float* rr = relu_src + row * D;
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
             m[c] = rr[i < D ? i : D - 1];
         }
     }
-    if (relu_bits) {  // one 64-bit word per 64 elements (a wave-uniform load) instead of a third full-width operand
+    if (MASKED && relu_bits) {  // one 64-bit word per 64 elements (a wave-uniform load) instead of a third full-width operand
         const int words = (D + 63) / 64;
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
@@ -96,7 +100,6 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
             m[c] = (w >> lane) & 1ull ? 1.f : 0.f;
         }
     }
-    const bool masked = relu_src != nullptr || relu_bits != nullptr;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MW; ++c) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
         const int i = lane + 64 * c;
         if (i < D) {
             float v = rs * (g[c] - m1 - h[c] * m2);
-            if (masked && !(m[c] > 0.f)) v = 0.f;
+            if (MASKED && !(m[c] > 0.f)) v = 0.f;
             o[i] = v;
         }
     }
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
 // ---- LayerNorm with optional residual input and grouped affine ------------------------------------
 // one wave per row, NW = ceil(D / 64) values per lane (template: rows are 20 .. 2816 wide in the models); branch-free
 // clamped loads so that all of a lane's loads are in flight together.
-template <int NW, bool AFFINE>
+template <int NW, bool AFFINE, bool WHOLE = false>   // WHOLE: D % 64 == 0, one address VGPR for all loads (see normalize_bwd_kernel)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ xhat,
@@ -571,12 +574,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < NW; ++c) {
         const int i = lane + 64 * c;
-        const int ic = i < D ? i : D - 1;
+        const int ic = WHOLE ? lane + (64 * c < D ? 64 * c : 0) : (i < D ? i : D - 1);
         long ro = ic;
         if (res_block > 0) {
             // block index of feature ic = lane + 64 c: wave-uniform c / (res_block / 64) when the blocks are whole multiples of the wave
             // (lanes beyond the row re-read its last feature: clamp the block index with them)
-            const int j = res_block % 64 == 0 ? min(64 * c, D - 64) / res_block : ic / res_block;
+            const int j = res_block % 64 == 0 ? (64 * c < D ? 64 * c : 0) / res_block : ic / res_block;
             ro += j * res_jstride;
         }
         v[c] = rr ? xr[ic] + rr[ro] : xr[ic];
@@ -759,8 +762,18 @@ int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D,
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
                      int D, hipStream_t st, const unsigned long long* relu_bits) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXCW, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXCW);
-#define AS_NORM_BWD(MW) \
-    hipLaunchKernelGGL(normalize_bwd_kernel<MW>, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, dx, rows, D, relu_bits)
+#define AS_NORM_BWD(MW)                                                                                                                \
+    do {                                                                                                                               \
+        if (relu_src || relu_bits)                                                                                                     \
+            hipLaunchKernelGGL((normalize_bwd_kernel<MW, true, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
+                               dx, rows, D, relu_bits);                                                                                \
+        else if (D % 64 == 0)                                                                                                          \
+            hipLaunchKernelGGL((normalize_bwd_kernel<MW, false, true>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
+                               dx, rows, D, relu_bits);                                                                                \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((normalize_bwd_kernel<MW, false, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
+                               dx, rows, D, relu_bits);                                                                                \
+    } while (0)
     if (D <= 128) AS_NORM_BWD(2);
     else if (D <= 256) AS_NORM_BWD(4);
     else if (D <= 64 * MAXC) AS_NORM_BWD(MAXC);
@@ -878,6 +891,9 @@ extern "C" int as_layernorm_fwd(const float* x, const float* res, const float* g
         if (gamma)                                                                                                                     \
             hipLaunchKernelGGL((layernorm_fwd_kernel<NW, true>), dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,  \
                                beta, y, xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f, 0, 0L);                                         \
+        else if (D % 64 == 0)                                                                                                          \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false, true>), dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res,  \
+                               gamma, beta, y, xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f, 0, 0L);                                  \
         else                                                                                                                           \
             hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma, \
                                beta, y, xhat, rstd, (long)rows, D, (long)group_rows, 1e-5f, 0, 0L);                                         \
@@ -899,9 +915,17 @@ extern "C" int as_layernorm_fwd_blockres(const float* x, const float* res, float
     const int D = per * block;
     AS_REQUIRE(D <= 64 * 44, AS_ERR_UNSUPPORTED, "as_layernorm_fwd_blockres: row length %d > %d", D, 64 * 44);
     const long total = (long)channels * rows;
-#define AS_LN_FWD(NW)                                                                                                              \
-    hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false>), dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res,         \
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block, (long)rows)
+#define AS_LN_FWD(NW)                                                                                                                \
+    do {                                                                                                                             \
+        if (block % 64 == 0)                                                                                                         \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false, true>), dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res, \
+                               (const float*)nullptr, (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block,      \
+                               (long)rows);                                                                                          \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<NW, false>), dim3(as_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, x, res,      \
+                               (const float*)nullptr, (const float*)nullptr, (float*)nullptr, xhat, rstd, total, D, 0L, 1e-5f, block,      \
+                               (long)rows);                                                                                          \
+    } while (0)
     if (D <= 64) AS_LN_FWD(1);
     else if (D <= 128) AS_LN_FWD(2);
     else if (D <= 256) AS_LN_FWD(4);
