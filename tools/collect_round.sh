@@ -19,7 +19,11 @@ step 200 $out/mk_stats.log rocprofv3 --kernel-trace --stats --output-format csv 
 step 200 $out/mk_fetch.log rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/mk_fetch -- python3 $R/tools/bench_metrics_kernels.py 10
 step 200 $out/mk_write.log rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/mk_write -- python3 $R/tools/bench_metrics_kernels.py 10
 step 400 $out/tstep.log rocprofv3 --kernel-trace --stats --output-format csv -d $out/tstep -- python3 $R/tools/profile_transformer_step.py 32 200 2
+python3 $R/tools/trace_by_shape.py $(ls -t $out/tstep/*/*_kernel_trace.csv | head -1) 45 > $out/transformer_step_by_shape.txt
+rm -f $out/tstep/*/*_kernel_trace.csv
 cd $R
+step 200 $out/gemm_ext_microbench.log python3 tools/bench_gemm_ext.py 10
+step 200 $out/attention_microbench.log python3 tools/bench_attention.py
 step 120 $out/metrics_kernels.log python3 tools/bench_metrics_kernels.py 50 --json $out/metrics_kernels.json
 step 120 $out/recurrence_in_step.log python3 tools/recurrence_stamps.py 50
 step 120 $out/recurrence_microbench.log python3 tools/bench_gru.py 20
