@@ -120,9 +120,10 @@ int check_dims(const as_dims* d, const char* who) {
     AS_REQUIRE(d->vocab > 0 && d->n_art > 0 && d->embed > 0 && d->hidden > 0 && d->n_samp > 0, AS_ERR_BAD_ARG,
                "%s: non-positive dimension (V=%d A=%d E=%d H=%d N=%d)", who, d->vocab, d->n_art, d->embed, d->hidden, d->n_samp);
     AS_REQUIRE(d->hidden <= 512, AS_ERR_UNSUPPORTED, "%s: hidden size %d > 512", who, d->hidden);
+    // hidden sizes 32 / 64 / 128 run the register-resident recurrence kernels, any other multiple of 4 (16-byte rows) the plain
+    // ones of gru.hip (several times slower per step)
     if (!d->simple)
-        AS_REQUIRE(d->hidden == 32 || d->hidden == 64 || d->hidden == 128, AS_ERR_UNSUPPORTED,
-                   "%s: GRU hidden size %d not in {32, 64, 128}", who, d->hidden);
+        AS_REQUIRE(d->hidden % 4 == 0, AS_ERR_UNSUPPORTED, "%s: GRU hidden size %d is not a multiple of 4", who, d->hidden);
     return 0;
 }
 

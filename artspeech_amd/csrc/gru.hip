@@ -583,6 +583,166 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_row_kernel(const float* __restr
     }
 }
 
+
+// ---- any hidden size (nn.GRU takes any, encoder_decoder/models.py:100-111): plain kernels for the sizes the register-
+// resident ones above are not built for (they hold W_hh in 96 VGPRs per lane at H = 128; at H = 256 it would be 192).  One
+// workgroup of 1024 threads per (utterance, direction) as above, h in LDS, W_hh streamed from L2 every step (768 KB per step
+// and workgroup at H = 256).  Same gates / y / dgi / dgh layouts and the same packed-sequence semantics; the reduction order
+// over k differs from the kernels above in the last bits.  Several times slower per step -- a correct fallback, not a tuned
+// path (measured: DESIGN.md 8).
+constexpr int GEN_THREADS = 1024;
+
+// Forward: four adjacent lanes share a hidden unit (j = tid / 4); lane q takes the 16-byte chunks q, q + 4, ... of the unit's
+// three W_hh rows -- the four lanes read 64 consecutive bytes of a row -- four chunks (12 global loads) in flight per pass,
+// and the three dot products are finished with the quad DPP sum of the kernels above.  H % 4 == 0.
+template <bool TRAIN, bool TOK>
+__global__ __launch_bounds__(GEN_THREADS) void gru_fwd_generic_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
+                                                                     long tok_stride, const float* __restrict__ w_hh,
+                                                                     const float* __restrict__ b_hh, const int* __restrict__ lengths,
+                                                                     int T, int H, float* __restrict__ y, float* __restrict__ gates,
+                                                                     int nd, int V) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // h double buffer [2][H]
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int q = tid & 3;
+    const int len = lengths[b];
+    for (long i = (long)len * H + tid; i < (long)T * H; i += GEN_THREADS)   // pad_packed_sequence: exact zeros
+        y[((long)b * T + i / H) * nd * H + dir * H + (i % H)] = 0.f;
+    for (int j = tid; j < 2 * H; j += GEN_THREADS) gsm[j] = 0.f;
+    __syncthreads();
+    if (len <= 0) return;
+    const float* wd = w_hh + (long)dir * 3 * H * H;
+    const float* bd = b_hh + (long)dir * 3 * H;
+    const int nch = H >> 2;   // 16-byte chunks per row
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? len - 1 - s : s;
+        const long frame = (long)b * T + t;
+        const float* hc = gsm + (s & 1) * H;
+        float* hn_ = gsm + ((s & 1) ^ 1) * H;
+        const float* gr;
+        if (TOK) {
+            int64_t v = tokens[(long)b * tok_stride + t];
+            if (V > 0) v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+            gr = gi + (v * nd + dir) * 3L * H;
+        } else {
+            gr = gi + (frame * nd + dir) * 3L * H;
+        }
+        for (int j = tid >> 2; j < H; j += GEN_THREADS / 4) {   // (the four lanes of a quad share j: the DPP sums are whole)
+            const float4* wr = reinterpret_cast<const float4*>(wd + (long)j * H);
+            const float4* wz = reinterpret_cast<const float4*>(wd + (long)(H + j) * H);
+            const float4* wn = reinterpret_cast<const float4*>(wd + (long)(2 * H + j) * H);
+            const float4* h4 = reinterpret_cast<const float4*>(hc);
+            float sr = 0.f, sz = 0.f, sn = 0.f;
+            for (int c0 = q; c0 < nch; c0 += 16) {
+                float4 a[4], c[4], e[4], hv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {      // branch-free: chunks beyond the row re-read its last one against a zero h
+                    const int cc = c0 + 4 * u;
+                    const int ci = cc < nch ? cc : nch - 1;
+                    a[u] = wr[ci]; c[u] = wz[ci]; e[u] = wn[ci];
+                    hv[u] = h4[ci];
+                    if (cc >= nch) hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sr += a[u].x * hv[u].x + a[u].y * hv[u].y + a[u].z * hv[u].z + a[u].w * hv[u].w;
+                    sz += c[u].x * hv[u].x + c[u].y * hv[u].y + c[u].z * hv[u].z + c[u].w * hv[u].w;
+                    sn += e[u].x * hv[u].x + e[u].y * hv[u].y + e[u].z * hv[u].z + e[u].w * hv[u].w;
+                }
+            }
+            sr = unit_sum<4>(sr) + bd[j];
+            sz = unit_sum<4>(sz) + bd[H + j];
+            sn = unit_sum<4>(sn) + bd[2 * H + j];
+            const float r = as_sigmoid(gr[j] + sr);
+            const float z = as_sigmoid(gr[H + j] + sz);
+            const float n = as_tanh(gr[2 * H + j] + r * sn);
+            const float hnew = (1.f - z) * n + z * hc[j];
+            if (q == 0) {
+                hn_[j] = hnew;
+                y[(frame * nd + dir) * H + j] = hnew;
+                if (TRAIN) {
+                    float* gp = gates + (frame * nd + dir) * 4L * H + j;
+                    gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = sn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Backward: the gate gradients of a step by one thread per hidden unit; then dh = dht * z + W_hh^T g with the 3H gate rows
+// dealt over four thread groups (lanes = consecutive hidden columns: a wave reads 256 consecutive bytes of a row, eight rows
+// in flight), the four partial sums meeting in LDS in a fixed order.
+__global__ __launch_bounds__(GEN_THREADS) void gru_bwd_generic_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                     const float* __restrict__ gates, const float* __restrict__ w_hh,
+                                                                     const int* __restrict__ lengths, int T, int H,
+                                                                     float* __restrict__ dgi, float* __restrict__ dgh) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // g [3H], dh carried [H], dht * z [H], partial sums [4][H]
+    float* gb = gsm;
+    float* dhb = gsm + 3 * H;
+    float* dhz = gsm + 4 * H;
+    float* part = gsm + 5 * H;
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int len = lengths[b];
+    for (long i = (long)len * 3 * H + tid; i < (long)T * 3 * H; i += GEN_THREADS) {   // padded frames feed time-batched GEMMs
+        const long t = i / (3 * H), c = i % (3 * H);
+        const long o = (((long)b * T + t) * 2 + dir) * 3 * H + c;
+        dgi[o] = 0.f;
+        dgh[o] = 0.f;
+    }
+    for (int j = tid; j < H; j += GEN_THREADS) dhb[j] = 0.f;
+    __syncthreads();
+    if (len <= 0) return;
+    const float* wd = w_hh + (long)dir * 3 * H * H;
+    // opposite to the forward walk; h_prev of frame t is the output of the frame visited NEXT (zero beyond the sequence)
+    const int dt = dir ? 1 : -1;
+    const int kq = tid >> 8, kl = tid & 255;   // row group (0..3), column within a block of 256
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? s : len - 1 - s;
+        const long frame = (long)b * T + t;
+        const bool has_prev = s + 1 < len;
+        for (int j = tid; j < H; j += GEN_THREADS) {
+            const float* gp = gates + (frame * 2 + dir) * 4L * H + j;
+            const float r = gp[0], z = gp[H], n = gp[2 * H], hn = gp[3 * H];
+            const float hprev = has_prev ? y[((frame + dt) * 2 + dir) * H + j] : 0.f;
+            const float dht = dhb[j] + dy[(frame * 2 + dir) * H + j];
+            const float dn = dht * (1.f - z);
+            const float dz = dht * (hprev - n);
+            const float dnt = dn * (1.f - n * n);
+            const float g_r = dnt * hn * r * (1.f - r);
+            const float g_z = dz * z * (1.f - z);
+            const float g_hn = dnt * r;
+            float* di = dgi + (frame * 2 + dir) * 3L * H + j;
+            float* dh = dgh + (frame * 2 + dir) * 3L * H + j;
+            di[0] = g_r; di[H] = g_z; di[2 * H] = dnt;
+            dh[0] = g_r; dh[H] = g_z; dh[2 * H] = g_hn;
+            gb[j] = g_r; gb[H + j] = g_z; gb[2 * H + j] = g_hn;
+            dhz[j] = dht * z;
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < H; k0 += 256) {
+            const int k = k0 + kl;
+            const int kc = k < H ? k : H - 1;
+            float acc = 0.f;
+            for (int i0 = kq; i0 < 3 * H; i0 += 32) {   // rows kq, kq + 4, ...: eight of them in flight
+                float wv[8], gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 4 * u;
+                    const int ic = i < 3 * H ? i : 3 * H - 1;
+                    wv[u] = wd[(long)ic * H + kc];
+                    gv[u] = i < 3 * H ? gb[ic] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += gv[u] * wv[u];
+            }
+            if (k < H) part[kq * H + k] = acc;
+        }
+        __syncthreads();
+        for (int k = tid; k < H; k += GEN_THREADS) dhb[k] = dhz[k] + ((part[k] + part[H + k]) + (part[2 * H + k] + part[3 * H + k]));
+        __syncthreads();
+    }
+}
+
 // Lanes per hidden unit.  Both layouts are built; measured at H = 128, B = 32, T = 200 (tools/bench_gru.py):
 // LPU = 4 (512 threads, two waves per SIMD): forward 0.55 us/step, backward 0.70; LPU = 2 (256 threads, one
 // wave per SIMD, 252 VGPRs): 0.56 / 0.77 -- the second wave hides the first one's LDS / DPP / transcendental
@@ -633,9 +793,17 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
         case 32: AS_GRU_FWD(32); break;
         case 64: AS_GRU_FWD(64); break;
         case 128: AS_GRU_FWD(128); break;
-        default:
-            as_set_error("as_gru_fwd: hidden size %d not in {32, 64, 128}", H);
-            return AS_ERR_UNSUPPORTED;
+        default: {   // any other hidden size: the plain kernels
+            const size_t gshm = (size_t)2 * H * sizeof(float);
+            AS_REQUIRE(H > 0 && H % 4 == 0 && gshm <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_gru_fwd: hidden size %d (a multiple of 4 up to 8192)", H);
+#define AS_GRU_GEN(TR, TK) \
+    hipLaunchKernelGGL((gru_fwd_generic_kernel<TR, TK>), grid, dim3(GEN_THREADS), gshm, st, gi, tokens, (long)tok_stride, w_hh, b_hh, lengths, T, H, y, gates, nd, V)
+            if (gates && tokens) AS_GRU_GEN(true, true);
+            else if (gates) AS_GRU_GEN(true, false);
+            else if (tokens) AS_GRU_GEN(false, true);
+            else AS_GRU_GEN(false, false);
+#undef AS_GRU_GEN
+        }
     }
 #undef AS_GRU_FWD
 #undef AS_GRU_LAUNCH
@@ -706,9 +874,12 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
         case 32: AS_GRU_BWD(32); break;
         case 64: AS_GRU_BWD(64); break;
         case 128: AS_GRU_BWD(128); break;
-        default:
-            as_set_error("as_gru_bidir_bwd: hidden size %d not in {32, 64, 128}", H);
-            return AS_ERR_UNSUPPORTED;
+        default: {   // any other hidden size: the plain kernel (never with a token table: as_gru_bwd_tokens_fits)
+            AS_REQUIRE(!tokens && dgi, AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: token sums need a hidden size in {32, 64, 128}");
+            const size_t gshm = (size_t)9 * H * sizeof(float);
+            AS_REQUIRE(H > 0 && H % 4 == 0 && gshm <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: hidden size %d (a multiple of 4 up to 1820)", H);
+            hipLaunchKernelGGL(gru_bwd_generic_kernel, grid, dim3(GEN_THREADS), gshm, st, dy, y, gates, w_hh, lengths, T, H, dgi, dgh);
+        }
     }
 #undef AS_GRU_BWD
 #undef AS_GRU_BWD_ROW
@@ -728,7 +899,7 @@ extern "C" int as_gru_bidir_bwd(const float* dy, const float* y, const float* ga
 // as_gru_bidir_bwd + as_token_segsum.
 bool as_gru_bwd_tokens_fits(int32_t V, int32_t H, int32_t T) {
     static const bool off = AS_DIAG_SET("AS_NO_GRU_TOKSUM");   // ablation: dgi + the segmented-sum kernel
-    return !off && ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) <= AS_GRU_TOK_LDS_MAX;
+    return !off && (H == 32 || H == 64 || H == 128) && ((long)V * 3 * H + 4 * H + T) * (long)sizeof(float) <= AS_GRU_TOK_LDS_MAX;
 }
 int as_gru_bidir_bwd_tokens(const float* dy, const float* y, const float* gates, const float* w_hh, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t H, float* dgh, const int64_t* tokens, int64_t tok_stride, int32_t V,

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define AS_ERR_BAD_ARG (-1)      /* null pointer / non-positive size / unsupported combination */
-#define AS_ERR_UNSUPPORTED (-2)  /* e.g. hidden size not in {32, 64, 128} */
+#define AS_ERR_UNSUPPORTED (-2)  /* e.g. a GRU hidden size that is not a multiple of 4 */
 #define AS_ERR_WORKSPACE (-3)    /* caller-provided workspace too small */
 
 #define AS_HEAD_HIDDEN 256 /* ArticulatorPredictor's fixed width (encoder_decoder/models.py:12-17) */
@@ -156,7 +156,10 @@ int as_artspeech_wait_head_grads(void* compute_stream, void* waiting_stream);
  *             tokens[b*tok_stride + t] (embedding folded in); else it is [B*T][2][3H].
  *   w_hh    : [2][3H][H], b_hh : [2][3H]
  *   y       : [B][T][2H]  (forward direction in [:H], reverse in [H:])
- *   gates   : NULL (inference) or [B][T][2][4][H] receiving r, z, n, (W_hn h + b_hn) for the backward */
+ *   gates   : NULL (inference) or [B][T][2][4][H] receiving r, z, n, (W_hn h + b_hn) for the backward
+ *   H       : 32, 64, 128 run register-resident kernels (W_hh stays in VGPRs for the whole sequence); any other multiple of 4
+ *             runs plain kernels that stream W_hh from L2 every step (same results up to the summation order, several
+ *             times slower per step) */
 int as_gru_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh,
                      const float* b_hh, const int32_t* lengths, int32_t B, int32_t T, int32_t H, float* y,
                      float* gates, void* stream);

@@ -55,7 +55,8 @@ def test_bad_arguments_are_reported(dev):
     assert L.as_gemm_f32(C.byref(g), None) == -1
     assert b"null" in L.as_last_error()
     x = torch.zeros(4, device=dev)
-    rc = L.as_gru_bidir_fwd(_lib.ptr(x), None, 0, _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 1, 48, _lib.ptr(x), None, None)
+    # (a hidden size beyond what the plain recurrence kernels' LDS state allows: refused before anything is launched)
+    rc = L.as_gru_bidir_fwd(_lib.ptr(x), None, 0, _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 1, 100000, _lib.ptr(x), None, None)
     assert rc == -2 and b"hidden size" in L.as_last_error()
 
 
@@ -351,6 +352,8 @@ def test_gemm_split_k_paths(dev, M, N, K, batch):
 # ------------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize("H,I,B,T,lengths", [
     (32, 16, 3, 7, [7, 4, 1]), (64, 24, 2, 11, [11, 11]), (128, 64, 4, 50, [50, 40, 30, 20]), (128, 256, 5, 33, [33, 32, 9, 2, 1]),
+    # hidden sizes the register-resident kernels are not built for: the plain kernels (nn.GRU takes any size, models.py:100-111)
+    (48, 16, 3, 9, [9, 5, 1]), (256, 64, 3, 40, [40, 17, 2]), (20, 8, 2, 6, [6, 3]), (300, 32, 2, 12, [12, 7]),
 ])
 def test_gru_layer_fwd_bwd(dev, H, I, B, T, lengths):
     from artspeech_amd import _lib
@@ -630,6 +633,41 @@ def test_artspeech_vs_oracle_more_than_1024_frames(dev, V):
     og = O.artspeech_bwd(o_dout, cache, A)
     for k, v in model.named_grad_views().items():
         assert_grad_close(v.cpu().numpy(), og[k], f"1280 frames, V={V}, vs oracle: {k}")
+
+
+@pytest.mark.parametrize("H", [48, 256])
+def test_artspeech_other_hidden_sizes_vs_oracle(dev, H):
+    """The reference accepts any hidden size (encoder_decoder/models.py:100-111); sizes outside {32, 64, 128} run the plain
+    recurrence kernels and, for layer 0, dgi + the segmented token sum instead of the in-kernel token table.  Contours, loss
+    and every parameter gradient against the oracle (which the reference's fixtures pin at H = 64 / 128)."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(H)
+    V, A = 21, 3
+    model = ArtSpeech(V, A, embed_dim=24, hidden_size=H)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, T = 4, 37
+    lengths = np.array([37, 30, 11, 1])
+    rng = np.random.RandomState(H)
+    x = rng.randint(1, V, (B, T))
+    tgt = rng.rand(B, T, A, 2, 50).astype(np.float32)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    loss = masked_euclidean_loss(out, T_(tgt, dev), lengths)
+    loss.backward()
+    o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
+    assert_close(out.detach().cpu().numpy(), o_out, what="contours")
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    og = O.artspeech_bwd(o_dout, cache, A)
+    for k, v in model.named_grad_views().items():
+        assert_grad_close(v.cpu().numpy(), og[k], f"hidden size {H} vs oracle: {k}")
+    with torch.no_grad():   # inference path (no saved gates)
+        out2 = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    assert torch.equal(out2, out.detach())
 
 
 # ------------------------------------------------------------------------------------------- metrics
