@@ -808,7 +808,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
         AS_STEP("grub.segsum", s_emb, as_sum_partials(ws + w.dgi0, (long)V * 6 * H, B, ws + w.dtab0, s_emb));
     else
         AS_STEP("grub.segsum", s_emb, as_token_segsum(ws + w.dgi0, tokens, tok_stride, T, R, 6 * H, V, ws + w.dtab0, s_emb, slab, SLAB_FLOATS));
-    if (E <= 256 && V <= 128) {  // embedding + input-projection gradients of layer 0 from the token sums: one small launch
+    if (E <= 256 && V <= 128 && (6 * H) % 16 == 0) {  // embedding + input-projection gradients of layer 0 from the token sums: one small launch
         AS_STEP("grub.dw_ih0", s_emb, as_emb_grads(ws + w.dtab0, P + L.embedding, P + L.w_ih[0], V, 6 * H, E, G + L.w_ih[0], G + L.b_ih[0],
                                                 G + L.embedding, s_emb));
     } else {

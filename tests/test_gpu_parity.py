@@ -635,7 +635,7 @@ def test_artspeech_vs_oracle_more_than_1024_frames(dev, V):
         assert_grad_close(v.cpu().numpy(), og[k], f"1280 frames, V={V}, vs oracle: {k}")
 
 
-@pytest.mark.parametrize("H", [48, 256])
+@pytest.mark.parametrize("H", [48, 256, 36])
 def test_artspeech_other_hidden_sizes_vs_oracle(dev, H):
     """The reference accepts any hidden size (encoder_decoder/models.py:100-111); sizes outside {32, 64, 128} run the plain
     recurrence kernels and, for layer 0, dgi + the segmented token sum instead of the in-kernel token table.  Contours, loss
