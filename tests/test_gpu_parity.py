@@ -321,6 +321,21 @@ def test_weight_gradient_stream_k(dev, M, N, K, batch, grouped):
     assert np.abs(outs[0][1].cpu().numpy() - aa.astype(np.float64).sum(1)).max() <= 2e-6 * np.sqrt(K) * np.abs(a).max() * 4
     plain = run(False)
     assert (outs[0][0] - plain[0]).abs().max().item() <= 4e-6 * scale * np.sqrt(K)
+    # accumulate: C += A^T B, through whole tiles and through the piece reduce alike
+    c0 = torch.randn(batch, M, N, device=dev)
+    acc = c0.clone()
+    g = _lib.Gemm()
+    g.A, g.B, g.C = ad.data_ptr(), bd.data_ptr(), acc.data_ptr()
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = 1, M, 1, N, N
+    g.a_batch, g.b_batch, g.c_batch = K * M, K * N, M * N
+    if grouped:
+        g.a_off = a_off.data_ptr()
+    g.accumulate = 1
+    g.splitk_ws, g.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+    torch.cuda.synchronize()
+    assert (acc - (c0 + outs[0][0])).abs().max().item() <= 2e-6 * scale
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(384, 128, 6400, 2), (256, 256, 4096, 3), (45, 64, 768, 1), (6400, 256, 768, 1), (100, 256, 2048, 5)])
