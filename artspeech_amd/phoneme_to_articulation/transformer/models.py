@@ -323,7 +323,7 @@ class ArtSpeechTransformer(nn.Module):
         """One group of ChannelProcessingLayers (:70-100) on affine-free normalised inputs -> (out, q): the out-projections
         [G, R, d] -- with cat = (A, per) concatenated over the `per` blocks of each channel, [A, R, per * d] (:133-162) -- and
         the projected queries, the residual (:98) that the LayerNorm consuming the pair adds."""
-        P, d = self.P, self.embed_dim
+        P = self.P
         tgt_idx, src_idx = self._groups[group]
         n = f"dec{l}_{group}_"
         if kv is None:

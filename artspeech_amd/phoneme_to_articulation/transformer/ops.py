@@ -374,19 +374,20 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
                            kv2=None):
     """Forward of ChannelBlocks (see there).  kv2 = (k2, v2) [G, Rs, d] each: the in-projected key / value side computed
     elsewhere (generate(): the memory side of the cross-attention blocks, once per call) -- inference only; xs is unused
-    then.  Returns (out, tensors for the backward or None, meta)."""
+    then.  Returns (out, q, tensors for the backward or None, meta): out without the residual, q the projected queries (the
+    residual a consuming LayerNorm adds), block-major [G, R, d] or, with cat, [A, per, R, d]."""
     tgt, src, B, heads, cat = cfg
     xt = _c(xt)
     q_w, q_b, in_w, in_b, o_w, o_b, ln_w, ln_b = (_c(p) for p in (q_w, q_b, in_w, in_b, o_w, o_b, ln_w, ln_b))
     G, d = q_w.shape[0], q_w.shape[-1]
-    Ct, R, _ = xt.shape
+    R = xt.shape[1]
     dev = xt.device
     L, st = _lib.lib(), _lib.stream_ptr()
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     assert kv2 is None or not training
     if kv2 is None:
         xs, k_w, k_b, v_w, v_b = (_c(p) for p in (xs, k_w, k_b, v_w, v_b))
-        Cs, Rs, _ = xs.shape
+        Rs = xs.shape[1]
         folds = ((q_w, q_b), (k_w, k_b), (v_w, v_b))
     else:
         Rs = kv2[0].shape[1]
