@@ -278,6 +278,48 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
     assert L.as_gemm_f32(C.byref(g), _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("A_,R,per,d", [(2, 37, 10, 256), (1, 9, 11, 256), (3, 5, 8, 192), (2, 6, 10, 260)])
+def test_wide_row_layernorm_kernels(dev, A_, R, per, d):
+    """The transformer's LayerNorms over 10 d / A d features (transformer/models.py:133-162, :441-447): affine-free forward
+    with a same-layout or a block-major residual, and the backward -- whose rows that are multiples of 256 floats take the
+    16-byte kernel, the others the scalar one (the forward keeps the scalar kernels: rowops.hip); against float64."""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(A_ * R + d)
+    D = per * d
+    x = rng.randn(A_, R, D).astype(np.float32)
+    q = rng.randn(A_ * per, R, d).astype(np.float32)
+    tx, tq = T_(x, dev), T_(q, dev)
+    xhat = torch.full((A_, R, D), float("nan"), device=dev)
+    rstd = torch.full((A_ * R,), float("nan"), device=dev)
+    _lib.check(L.as_layernorm_fwd_blockres(_lib.ptr(tx), _lib.ptr(tq), _lib.ptr(xhat), _lib.ptr(rstd), A_, R, per, d, _lib.stream_ptr()),
+               "as_layernorm_fwd_blockres")
+    z = x.astype(np.float64) + q.reshape(A_, per, R, d).transpose(0, 2, 1, 3).reshape(A_, R, D)
+    mu, var = z.mean(-1, keepdims=True), z.var(-1, keepdims=True)
+    ref = (z - mu) / np.sqrt(var + 1e-5)
+    assert_close(xhat.cpu().numpy(), ref, rtol=2e-5, atol=2e-5, what="LN(x + block-major residual)")
+    assert_close(rstd.cpu().numpy().reshape(A_, R, 1), 1 / np.sqrt(var + 1e-5), rtol=2e-5, atol=0, what="rstd")
+    # same-layout residual through as_layernorm_fwd
+    r2 = rng.randn(A_, R, D).astype(np.float32)
+    tr2 = T_(r2, dev)
+    xhat2 = torch.full((A_, R, D), float("nan"), device=dev)
+    _lib.check(L.as_layernorm_fwd(_lib.ptr(tx), _lib.ptr(tr2), None, None, None, _lib.ptr(xhat2), _lib.ptr(rstd), A_ * R, D, 0,
+                                  _lib.stream_ptr()), "as_layernorm_fwd")
+    z2 = x.astype(np.float64) + r2
+    ref2 = (z2 - z2.mean(-1, keepdims=True)) / np.sqrt(z2.var(-1, keepdims=True) + 1e-5)
+    assert_close(xhat2.cpu().numpy(), ref2, rtol=2e-5, atol=2e-5, what="LN(x + residual)")
+    # backward of the affine-free LayerNorm
+    dy = rng.randn(A_, R, D).astype(np.float32)
+    tdy = T_(dy, dev)
+    dx = torch.full((A_, R, D), float("nan"), device=dev)
+    _lib.check(L.as_layernorm_bwd(_lib.ptr(tdy), _lib.ptr(xhat2), _lib.ptr(rstd), None, _lib.ptr(dx), A_ * R, D, _lib.stream_ptr()),
+               "as_layernorm_bwd")
+    g, h = dy.astype(np.float64), ref2
+    rs = 1 / np.sqrt(z2.var(-1, keepdims=True) + 1e-5)
+    want = rs * (g - g.mean(-1, keepdims=True) - h * (g * h).mean(-1, keepdims=True))
+    assert_close(dx.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max(), what="LayerNorm backward")
+
+
 @pytest.mark.parametrize("M,N,K,batch,grouped", [(256, 256, 1024, 70, False), (200, 132, 2048, 75, True), (256, 256, 6400, 110, False),
                                                   (128, 256, 800, 300, False)])
 def test_weight_gradient_stream_k(dev, M, N, K, batch, grouped):
