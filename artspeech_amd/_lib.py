@@ -52,7 +52,7 @@ class Gemm(C.Structure):
                 ("bias_off", C.c_void_p), ("precision", C.c_int32), ("b_kshift_batch", C.c_int32), ("cu_budget", C.c_int32),
                 ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_batch", C.c_int64), ("res_off", C.c_void_p),
                 ("mask_bits", C.c_void_p), ("mask_batch", C.c_int64), ("relu_bits", C.c_void_p), ("relu_bits_batch", C.c_int64),
-                ("k_seg", C.c_int32), ("a_seg_off", C.c_void_p), ("b_seg_off", C.c_void_p)]
+                ("k_seg", C.c_int32), ("a_seg_off", C.c_void_p), ("b_seg_off", C.c_void_p), ("k_tri", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

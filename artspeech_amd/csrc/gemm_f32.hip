@@ -44,6 +44,7 @@ struct GemmK {
     unsigned* relu_bits; long relu_bits_batch;
     // optional segmented reduction (as_gemm.k_seg): per (batch, segment) element offsets of the A rows and the B panel
     int k_seg; const long* a_seg_off; const long* b_seg_off;
+    int k_tri;   // as_gemm.k_tri: the A operand is exactly zero for k < i (1) or k > i (2): a tile's reduction range shrinks
 };
 
 // device-scope accesses for data handed between workgroups of one launch (they may sit on different XCDs, whose L2s are not
@@ -199,13 +200,23 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         const int xy = wrem - x.ks * per_split;
         x.xy = xy;
         x.tn_idx = xy / tiles_m;
-        x.m0 = (xy - x.tn_idx * tiles_m) * BM;
+        int tm = xy - x.tn_idx * tiles_m;
+        // triangular A: an M-tile's reduction length depends on its position, and a workgroup that strides the work list by a
+        // multiple of the tiles per batch member would always get the same position (the longest one sets the launch time):
+        // rotate the M-tile by the round, so that every workgroup sees every length.  (A bijection on a batch member's tiles
+        // as long as they all sit in one round: grid % tiles per batch member == 0, else no rotation.)
+        if (g.k_tri != 0 && tiles_n == 1 && g.splitk == 1 && gridDim.x % tiles_m == 0) tm = (tm + (int)(w / gridDim.x)) % tiles_m;
+        x.m0 = tm * BM;
         x.n0 = x.tn_idx * BN;
         x.A = g.A + (g.a_off ? g.a_off[x.bz] : (long)x.bz * g.a_batch);
         x.B = g.B + (g.b_off ? g.b_off[x.bz] : (long)x.bz * g.b_batch);
         x.C = g.C + (g.c_off ? g.c_off[x.bz] : (long)x.bz * g.c_batch);
         x.kbeg = x.ks * g.kchunk;
         x.kend = min(g.K, x.kbeg + g.kchunk);
+        // triangular A (causal attention probabilities and their gradients): the k-tiles in which every row of this tile is zero
+        // are not visited -- the skipped products are exact zeros
+        if (g.k_tri == 1) x.kbeg = max(x.kbeg, (x.m0 / BK) * BK);
+        else if (g.k_tri == 2) x.kend = min(x.kend, ((x.m0 + BM + BK - 1) / BK) * BK);
         x.kshift = g.b_kshift + x.bz * g.b_kshift_batch;
         return x;
     };
@@ -768,7 +779,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     AS_REQUIRE(g->act >= 0 && g->act <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
     const bool a_kc = g->a_k == 1, b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
-    if (!a_kc && !b_kc) {  // weight-gradient shapes: the kernel of wgrad_f32.hip
+    if (!a_kc && !b_kc && g->k_tri == 0) {  // weight-gradient shapes: the kernel of wgrad_f32.hip (it does not know k_tri)
         const int taken = as_wgrad_try(g, (hipStream_t)stream);
         if (taken != 0) return taken < 0 ? taken : 0;
     }
@@ -789,6 +800,10 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.res = g->res; k.res_ld = g->res_ld; k.res_batch = g->res_batch; k.res_off = (const long*)g->res_off;
     k.mask_bits = g->mask_bits; k.mask_batch = g->mask_batch; k.relu_bits = g->relu_bits; k.relu_bits_batch = g->relu_bits_batch;
     k.k_seg = g->k_seg; k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
+    k.k_tri = g->k_tri;
+    AS_REQUIRE(g->k_tri >= 0 && g->k_tri <= 2, AS_ERR_BAD_ARG, "as_gemm_f32: k_tri=%d", g->k_tri);
+    AS_REQUIRE(g->k_tri == 0 || (!g->colsum && !g->splitk_ws && g->precision == 0 && g->k_seg == 0), AS_ERR_BAD_ARG,
+               "as_gemm_f32: k_tri goes with the general kernel only (no colsum, splitk_ws, split precision or k_seg)");
     const bool epi_ops = g->res || g->mask_bits || g->relu_bits, segmented = g->k_seg > 0;
     AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && g->precision == 0 && (a_kc || b_kc)),
                AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg go with the general kernel only (no colsum, splitk_ws, "

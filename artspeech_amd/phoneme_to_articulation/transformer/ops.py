@@ -260,6 +260,10 @@ def _key_major_mask(attn_mask, Tk, T):
     B = attn_mask.shape[0]
     mt = torch.zeros((B, (Tk + 31) // 32 * 32, T), dtype=torch.float32, device=attn_mask.device)
     mt[:, :Tk] = attn_mask.to(torch.float32).transpose(1, 2)
+    # causal: every key AFTER the query is masked with -inf for every utterance -> P[q][k] == 0 exactly for k > q (one check per
+    # mask tensor; the backward's GEMMs over P^T / dS^T then skip the k-tiles that hold nothing but those zeros, as_gemm.k_tri)
+    upper = torch.triu(torch.ones(T, Tk, dtype=torch.bool, device=attn_mask.device), diagonal=1)
+    mt.causal = bool(torch.isneginf(attn_mask.to(torch.float32))[:, upper].all().item()) if bool(upper.any()) else False
     _MASK_T[k] = (weakref.ref(attn_mask, lambda _r, k=k: _MASK_T.pop(k, None)), tag, mt)
     return mt
 
@@ -275,7 +279,8 @@ def _z_tables(dev, G, B, T, Tk, d, heads):
 def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
     """Multi-head attention core on projected tensors (nn.MultiheadAttention semantics, float additive masks):
     Q [G, B*T, d], K/V [G, B*Tk, d] -> ctx [G, B*T, d];  P = softmax(Q_h K_h^T / sqrt(dh) + attn_mask[b] + kpm[b]).
-    Returns (ctx, tensors to keep for attention_backward or None, scale)."""
+    Returns (ctx, tensors to keep for attention_backward or None, scale, causal) -- causal: the mask is -inf above the diagonal
+    for every utterance, i.e. the probabilities there are exact zeros (what attention_backward's GEMMs then skip)."""
     G, R, d = Q.shape
     Rk = K.shape[1]
     T, Tk, dh = R // B, Rk // B, d // heads
@@ -291,7 +296,8 @@ def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
         mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
         _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
                                       _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
-        return out, ((Q, K, V, Pt, out) if training else None), scale
+        causal = mt is not None and bool(getattr(mt, "causal", False))
+        return out, ((Q, K, V, Pt, out) if training else None), scale, causal
     zq, zk, zs = _z_tables(dev, G, B, T, Tk, d, heads)
     P = torch.empty((Z, T, Tk), dtype=torch.float32, device=dev)
     _gemm(A=Q, B=K, C=P, M=T, N=Tk, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tk, batch=Z, a_off=zq, b_off=zk, c_off=zs)
@@ -299,11 +305,12 @@ def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
     _lib.check(L.as_attn_softmax(_lib.ptr(P), Z, T, Tk, heads, B, scale, _lib.ptr(am), _lib.ptr(km), _lib.stream_ptr()), "as_attn_softmax")
     out = torch.empty_like(Q)
     _gemm(A=P, B=V, C=out, M=T, N=dh, K=Tk, a_i=Tk, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
-    return out, ((Q, K, V, P) if training else None), scale
+    return out, ((Q, K, V, P) if training else None), scale, False
 
 
-def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None):
-    """(dQ, dK, dV) of attention_forward; the three may be handed in (contiguous slices of a caller's buffer)."""
+def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None, causal=False):
+    """(dQ, dK, dV) of attention_forward; the three may be handed in (contiguous slices of a caller's buffer).  causal: the
+    forward's additive mask was -inf above the diagonal for every utterance (attention_forward found out)."""
     Q, K, V = saved[:3]
     G, R, d = Q.shape
     Rk = K.shape[1]
@@ -321,8 +328,11 @@ def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None):
         # second pass over the scores
         Pt, out = saved[3:]
         dPt = torch.empty_like(Pt)
+        # causal mask: P^T[key][q] and dS^T[key][q] are exact zeros for q < key -- the three products below skip those k-tiles
+        lower = dict(k_tri=1, precision=0) if causal else {}   # reduction over q, rows = keys: zero for q < key
+        upper = dict(k_tri=2, precision=0) if causal else {}   # reduction over keys, rows = q: zero for key > q
         # dV = P^T dctx
-        _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+        _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk, **lower)
         if FUSED_DS:
             # dS^T = P^T o (V dctx^T - D) * scale in one kernel: dP is never formed
             _lib.check(_lib.lib().as_attention_bwd_ds(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T,
@@ -333,8 +343,8 @@ def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None):
             _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B,
                                                         heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
         # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
-        _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq)
-        _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk)
+        _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq, **upper)
+        _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk, **lower)
         return dQ, dK, dV
     P = saved[3]
     dP = torch.empty_like(P)
@@ -354,16 +364,17 @@ class Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Q, K, V, attn_mask, kpm, B, heads):
-        out, saved, scale = attention_forward(_c(Q), _c(K), _c(V), attn_mask, kpm, B, heads, any(ctx.needs_input_grad[:3]))
+        out, saved, scale, causal = attention_forward(_c(Q), _c(K), _c(V), attn_mask, kpm, B, heads, any(ctx.needs_input_grad[:3]))
         if saved is not None:
             ctx.save_for_backward(*saved)
         ctx.meta = (B, heads, scale)
+        ctx.causal = causal
         return out
 
     @staticmethod
     def backward(ctx, dctx):
         saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
-        return (*attention_backward(saved, *ctx.meta, dctx), None, None, None, None)
+        return (*attention_backward(saved, *ctx.meta, dctx, causal=ctx.causal), None, None, None, None)
 
 
 def _ptr(t, off_floats=0):
@@ -430,7 +441,7 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
         if kv is not None:
             _gemm(A=kv, B=in_w, C=kv2, bias=in_b, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=2 * G, a_batch=Rs * d,
                   b_off=w_off[G:], c_batch=Rs * d, bias_off=bi_off[G:])
-    att, att_saved, scale = attention_forward(q2, _c(kv2[0]), _c(kv2[1]), attn_mask, kpm, B, heads, training)
+    att, att_saved, scale, causal = attention_forward(q2, _c(kv2[0]), _c(kv2[1]), attn_mask, kpm, B, heads, training)
     # out-projection, straight into its final layout.  The residual `q + out` (:98) is NOT added here: every group's output
     # goes into a LayerNorm only, which adds q as it reads (NormalizeRes / LayerNormAffine) -- no pass of its own, and the
     # reference's order (sum + bias) + q.  (As the accumulators' initial value it costs the GEMM 110 us per 110-block launch
@@ -453,7 +464,7 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
     if not training:
         return out, q_out, None, None
     return (out, q_out, (xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits, *att_saved),
-            (tgt, src, B, heads, cat, scale, ldo))
+            (tgt, src, B, heads, cat, scale, ldo, causal))
 
 
 class ChannelBlocks(torch.autograd.Function):
@@ -497,7 +508,7 @@ class ChannelBlocks(torch.autograd.Function):
         saved = ctx.saved_tensors   # read ONCE (torch.utils.checkpoint's unpack hooks allow a single access)
         xt, xs, q_w, k_w, v_w, ln_w, ln_b, W3, in_w, o_w, q, kv, att, qbits, kvbits = saved[:15]
         att_saved = saved[15:]
-        tgt, src, B, heads, cat, scale, ldo = ctx.meta
+        tgt, src, B, heads, cat, scale, ldo, causal = ctx.meta
         G, d = q_w.shape[0], q_w.shape[-1]
         ncb = (d + 31) // 32
         (Ct, R, _), (Cs, Rs, _) = xt.shape, xs.shape
@@ -535,7 +546,7 @@ class ChannelBlocks(torch.autograd.Function):
         dp2 = new(3, G, R, d) if same else None
         dq2 = dp2[0] if same else new(G, R, d)
         dkv2 = dp2[1:] if same else new(2, G, Rs, d)
-        attention_backward(att_saved, B, heads, scale, datt, dQ=dq2, dK=dkv2[0], dV=dkv2[1])
+        attention_backward(att_saved, B, heads, scale, datt, dQ=dq2, dK=dkv2[0], dV=dkv2[1], causal=causal)
         del datt
         # ---- in-projection: weight gradients into the stacked [G, 3d, d] tensor; input gradients through the ReLU masks of
         # q / k / v, the query's together with the gradient that arrives over the residual (`dout` itself)

@@ -241,6 +241,12 @@ typedef struct as_gemm {
        from the segment's start).  Sums the input gradients of all blocks that read one source channel in ONE GEMM
        (dx[c] = sum_g dz[g] W[g] over the blocks g with src[g] = c) instead of per-block partial tensors + a reduce pass. */
     int32_t k_seg; const int64_t* a_seg_off; const int64_t* b_seg_off;
+    /* optional: the A operand is EXACTLY zero below (1: A[i][k] == 0 for k < i) or above (2: for k > i) its diagonal, i and k
+       counted in the same index space -- the key-major probabilities P^T[key][q] of a causally masked attention and their
+       gradients (transformer/models.py:380-387: both decoder masks are causal).  An output tile then only walks the k-tiles
+       in which one of its rows can be non-zero; the skipped products are exact zeros (a non-finite B element in a skipped
+       range no longer turns 0 * inf into NaN).  General kernel only, like k_seg. */
+    int32_t k_tri;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 

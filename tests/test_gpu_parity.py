@@ -278,6 +278,42 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
     assert L.as_gemm_f32(C.byref(g), _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("T,dh,Z", [(200, 64, 40), (77, 16, 9), (256, 32, 5)])
+def test_gemm_triangular_reduction_range(dev, T, dh, Z):
+    """as_gemm.k_tri: the key-major probabilities P^T[key][q] of a causally masked attention (and dS^T) are exact zeros for
+    q < key; the three backward products skip the k-tiles that hold only those zeros -- bit-identical to the full products."""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(T + dh)
+    pt = rng.rand(Z, T, T).astype(np.float32)             # [z][key][q]
+    pt *= np.triu(np.ones((T, T), np.float32))            # zero for q < key
+    x = rng.randn(Z, T, dh).astype(np.float32)
+    t_pt, t_x = T_(pt, dev), T_(x, dev)
+
+    def run(k_tri, **kw):
+        out = torch.full((Z, T, dh), float("nan"), device=dev)
+        g = _lib.Gemm()
+        g.A, g.B, g.C = t_pt.data_ptr(), t_x.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.batch = T, dh, T, Z
+        g.b_j, g.b_k, g.ldc = 1, dh, dh
+        g.a_batch, g.b_batch, g.c_batch = T * T, T * dh, T * dh
+        g.k_tri = k_tri
+        for k, v in kw.items():
+            setattr(g, k, v)
+        _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+        torch.cuda.synchronize()
+        return out
+
+    # rows = keys, reduction over q (dV = P^T dctx, dK = dS^T Q): zero for k < i
+    full, tri = run(0, a_i=T, a_k=1), run(1, a_i=T, a_k=1)
+    assert torch.equal(full, tri)
+    assert_close(tri.cpu().numpy(), np.einsum("zkq,zqc->zkc", pt.astype(np.float64), x), rtol=2e-5, atol=2e-5 * np.sqrt(T), what="P^T x")
+    # rows = queries, reduction over keys, A read through its transpose (dQ = dS K): zero for k > i
+    full, tri = run(0, a_i=1, a_k=T), run(2, a_i=1, a_k=T)
+    assert torch.equal(full, tri)
+    assert_close(tri.cpu().numpy(), np.einsum("zkq,zkc->zqc", pt.astype(np.float64), x), rtol=2e-5, atol=2e-5 * np.sqrt(T), what="P x")
+
+
 @pytest.mark.parametrize("A_,R,per,d", [(2, 37, 10, 256), (1, 9, 11, 256), (3, 5, 8, 192), (2, 6, 10, 260)])
 def test_wide_row_layernorm_kernels(dev, A_, R, per, d):
     """The transformer's LayerNorms over 10 d / A d features (transformer/models.py:133-162, :441-447): affine-free forward

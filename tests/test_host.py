@@ -368,7 +368,7 @@ def test_ctypes_structs_match_the_header_layout():
 int main(void) {
     printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(as_opts), offsetof(as_opts, dout_presigmoid), sizeof(as_gemm), offsetof(as_gemm, precision),
            offsetof(as_gemm, b_kshift_batch), sizeof(as_dims), offsetof(as_gemm, cu_budget), offsetof(as_gemm, res_off),
-           offsetof(as_gemm, mask_batch), offsetof(as_gemm, b_seg_off));
+           offsetof(as_gemm, mask_batch), offsetof(as_gemm, k_tri));
     return 0;
 }
 """
@@ -381,7 +381,7 @@ int main(void) {
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     want = [C.sizeof(_lib.Opts), _lib.Opts.dout_presigmoid.offset, C.sizeof(_lib.Gemm), _lib.Gemm.precision.offset,
             _lib.Gemm.b_kshift_batch.offset, C.sizeof(_lib.Dims), _lib.Gemm.cu_budget.offset, _lib.Gemm.res_off.offset,
-            _lib.Gemm.mask_batch.offset, _lib.Gemm.b_seg_off.offset]
+            _lib.Gemm.mask_batch.offset, _lib.Gemm.k_tri.offset]
     assert got == want, (got, want)
 
 

@@ -56,6 +56,18 @@ cases = {
     "channel sums, segmented K = 10 d (ext)": (lambda: gemm(A=x, B=w, C=dx, M=R, N=d, K=per * d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=A_,
                                                               c_batch=R * d, k_seg=d, a_seg_off=aseg, b_seg_off=bseg), G),
 }
+# attention backward products of one interaction group: Z = G * B * heads slices of P^T [Tk][T] against [T][dh] operands
+Tq, dh, Z = 200, 64, 110 * 32 * 4
+pt = torch.triu(torch.rand(Tq, Tq, device=dev)).repeat(Z, 1, 1).contiguous()   # zero for q < key (causal)
+xa = torch.randn(Z, Tq, dh, device=dev)
+oa = torch.empty(Z, Tq, dh, device=dev)
+att = dict(M=Tq, N=dh, K=Tq, b_j=1, b_k=dh, ldc=dh, batch=Z, a_batch=Tq * Tq, b_batch=Tq * dh, c_batch=Tq * dh)
+cases.update({
+    "attention bwd, P^T x (dV / dK), full": (lambda: gemm(A=pt, B=xa, C=oa, a_i=Tq, a_k=1, **att), None),
+    "attention bwd, P^T x (dV / dK), k_tri = 1": (lambda: gemm(A=pt, B=xa, C=oa, a_i=Tq, a_k=1, k_tri=1, **att), None),
+    "attention bwd, P x (dQ), full": (lambda: gemm(A=pt, B=xa, C=oa, a_i=1, a_k=Tq, **att), None),
+    "attention bwd, P x (dQ), k_tri = 2": (lambda: gemm(A=pt, B=xa, C=oa, a_i=1, a_k=Tq, k_tri=2, **att), None),
+})
 print(f"G={G} R={R} d={d}: {2 * R * d * d * G / 1e9:.1f} GFLOP per launch; {iters} launches each")
 for _ in range(30):   # clocks and caches settle before the first case is timed
     gemm(A=x, B=w, C=out, ldc=d, c_batch=R * d, **nn)
@@ -70,4 +82,5 @@ for name, (fn, blocks) in cases.items():
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
-    print(f"{name:52s} {us:8.1f} us  {2 * R * d * d * blocks / us / 1e6:6.1f} TF/s", flush=True)
+    flops = 2 * R * d * d * blocks if blocks else 2.0 * Tq * Tq * dh * Z   # (attention rows: dense-equivalent FLOPs)
+    print(f"{name:52s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF/s", flush=True)
