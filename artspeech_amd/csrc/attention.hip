@@ -29,8 +29,10 @@ struct AttnK {
     const float* mask_t;  // [B][Tk rounded up to 32][T] additive, KEY-major (transposed and padded by the caller) or nullptr
     const float* kpm;     // [B][Tk] additive or nullptr
     float* lse;           // [Z][T] row maximum + log of the row sum (for a backward that recomputes P) or nullptr
-    float* probs_t;       // [Z][Tk][T] the probabilities, KEY-major (what the unfused backward consumes), or nullptr
+    float* probs_t;       // [Z][Tk][tp] the probabilities, KEY-major (what the unfused backward consumes), or nullptr
     int B, heads, T, Tk, d;
+    int tp;               // row pitch of probs_t: T rounded up to 32 floats, so that a strip's 128-byte row segment is one cache line
+                          // (at the natural pitch of T = 200 floats = 800 B every segment straddles two lines)
     float scale;
 };
 
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (a.probs_t) {  // training: P^T rows are contiguous in q, i.e. across the lanes (uniform row pointer + lane offset)
-            float* pz = a.probs_t + z * (long)a.Tk * a.T;
-            const int poff = q + 4 * lh * a.T;
+            float* pz = a.probs_t + z * (long)a.Tk * a.tp;
+            const int poff = q + 4 * lh * a.tp;
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
-                    if (q < a.T && ku + 4 * lh < a.Tk) (pz + (long)ku * a.T)[poff] = sacc[blk][r];
+                    if (q < a.T && ku + 4 * lh < a.Tk) (pz + (long)ku * a.tp)[poff] = sacc[blk][r];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
 // Replaces a 200 x 200 x 64 grouped GEMM (4 ragged tiles, 2-step reduction) + the softmax-backward sweep: the dP tensor
 // (2.25 GB per interaction group) is neither written nor read.
 struct AttnDsK {
-    const float* V; const float* dctx; const float* ctx; const float* probs_t; float* ds_t;
-    int B, heads, T, Tk, d;
+    const float* V; const float* dctx; const float* ctx; const float* probs_t; float* ds_t;   // probs_t, ds_t: [Z][Tk][tp]
+    int B, heads, T, Tk, d, tp;
     float scale;
 };
 
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
         *reinterpret_cast<float4*>(Vs + row * LD + c4 * 4) = v;
     }
     __syncthreads();
-    const float* pz = a.probs_t + z * (long)a.Tk * a.T;
-    float* dz = a.ds_t + z * (long)a.Tk * a.T;
+    const float* pz = a.probs_t + z * (long)a.Tk * a.tp;
+    float* dz = a.ds_t + z * (long)a.Tk * a.tp;
     const int strips = (a.T + 31) / 32;
     for (int strip = wave; strip < strips; strip += ATT_THREADS / 64) {
         const int q = strip * 32 + l31;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
         D += __shfl_xor(D, 32, 64);
         // uniform row pointer + one of two per-lane 32-bit offsets (as in the forward: per-element 64-bit addresses would be
         // hoisted out of the strip loop, two VGPRs each).  Rows are clamped on the uniform side, so every load is in bounds.
-        const int off0 = qc, off4 = qc + 4 * lh * a.T;
+        const int off0 = qc, off4 = qc + 4 * lh * a.tp;
         // the probabilities of block blk + 1 go in flight BEFORE the matrix work of block blk: a block's loads queue behind the
         // previous block's stores (vector memory operations retire in order), so one block of look-ahead is what lets a
         // wave's memory pipe work while its 32 MFMAs run (before: load -> MFMAs -> store, block after block: 2.2 ms per
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
                 // (recomputed per use on the scalar unit: hoisted out of the strip loop, the 2 x 16 NB row pointers are
                 // ~450 SGPRs that end up in VGPR lanes and scratch)
                 asm volatile("" : "+s"(ku));
-                const float* row = pz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
+                const float* row = pz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.tp;
                 pv[r] = row[ku + 4 < a.Tk ? off4 : off0];
             }
         };
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_kernel(AttnDsK a) {
                 asm volatile("" : "+s"(ku));
                 const bool both = ku + 4 < a.Tk;                    // uniform: rows ku and ku + 4 both exist
                 const bool mine = both || (lh == 0 && ku < a.Tk);   // this half-wave's key row exists
-                float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.T;
+                float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.tp;
                 if (mine && q < a.T) row[both ? off4 : off0] = pv[r] * (acc[r] - D) * a.scale;
             }
         };
@@ -333,6 +335,171 @@ int launch_attn_ds(const AttnDsK& k, long Z, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_ds_kernel<DH, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     AS_REQUIRE(attr == hipSuccess, (int)attr, "as_attention_bwd_ds: cannot reserve %zu bytes of LDS: %s", shm, hipGetErrorString(attr));
     hipLaunchKernelGGL((attn_ds_kernel<DH, NB>), dim3((unsigned)Z), dim3(ATT_THREADS), shm, st, k);
+    return 0;
+}
+
+
+// The same under a CAUSAL mask (P^T[key][q] == 0 for q < key): only the (query strip s, key block kb) pairs with kb <= s hold
+// anything, 28 of 49 at T = Tk = 200.  With a strip per wave the wave of the last strip would still walk all its blocks and set
+// the workgroup's time; a block of dS^T depends on nothing but its own strip's dctx rows and D, so the PAIRS are the work items
+// here: the non-empty ones are dealt evenly over the eight waves (3.5 each), the empty ones are zero-filled (the GEMMs that
+// follow read parts of them).  D[q] of all queries is computed once per workgroup into LDS.  T, Tk <= 256.
+template <int DH>
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_ds_causal_kernel(AttnDsK a) {
+    constexpr int LD = DH + 4;
+    constexpr int HS = DH / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nb = (a.Tk + 31) / 32, strips = (a.T + 31) / 32;   // <= 8 each
+    float* Vs = smem;                       // [32 nb][LD]
+    float* Dq = smem + 32 * nb * LD;        // [32 strips]
+    int* items = reinterpret_cast<int*>(Dq + 32 * strips);   // [strips * nb] pairs s * 8 + kb, the non-empty ones first; [64] = their count
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long z = blockIdx.x;
+    const int h = (int)(z % a.heads);
+    const int b = (int)((z / a.heads) % a.B);
+    const long g = z / ((long)a.heads * a.B);
+    const long qbase = ((g * a.B + b) * (long)a.T) * a.d + (long)h * DH;
+    const long kbase = ((g * a.B + b) * (long)a.Tk) * a.d + (long)h * DH;
+    constexpr int V4 = DH / 4;
+    for (int i = tid; i < 32 * nb * V4; i += ATT_THREADS) {
+        const int row = i / V4, c4 = i - row * V4;
+        const bool ok = row < a.Tk;
+        float4 v = *reinterpret_cast<const float4*>(a.V + kbase + (long)(ok ? row : 0) * a.d + c4 * 4);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Vs + row * LD + c4 * 4) = v;
+    }
+    if (wave < strips) {   // D[q] = sum_c dctx[q][c] ctx[q][c] of strip `wave` (each half-wave sums its half of the row)
+        const int q = wave * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        const float* gp = a.dctx + qbase + (long)qc * a.d + lh * HS;
+        const float* op = a.ctx + qbase + (long)qc * a.d + lh * HS;
+        float D = 0.f;
+#pragma unroll
+        for (int s = 0; s < HS; s += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(gp + s);
+            const float4 o = *reinterpret_cast<const float4*>(op + s);
+            D += t.x * o.x + t.y * o.y + t.z * o.z + t.w * o.w;
+        }
+        D += __shfl_xor(D, 32, 64);
+        if (lh == 0) Dq[q] = D;
+    }
+    if (tid == 0) {
+        int n = 0;
+        for (int s = 0; s < strips; ++s)
+            for (int kb = 0; kb < nb && kb <= s; ++kb) items[n++] = s * 8 + kb;
+        items[64] = n;
+        for (int s = 0; s < strips; ++s)
+            for (int kb = s + 1; kb < nb; ++kb) items[n++] = s * 8 + kb;
+    }
+    __syncthreads();
+    const int n_comp = items[64], n_total = strips * nb;
+    const float* pz = a.probs_t + z * (long)a.Tk * a.tp;
+    float* dz = a.ds_t + z * (long)a.Tk * a.tp;
+    // A wave takes a CONTIGUOUS run of the non-empty pairs (strip-major order: at most two strips per run, so the strip's dctx rows
+    // are loaded once or twice per wave) and keeps the next pair's probabilities in flight under the current pair's MFMAs: a
+    // pair's loads queue behind the previous pair's stores (vector memory operations retire in order), one pair of look-ahead is
+    // what keeps the memory pipe busy.  Its share of the empty pairs is zero-filled at the end.
+    const int c0 = wave * n_comp / 8, c1 = (wave + 1) * n_comp / 8;
+    const int nz = n_total - n_comp;
+    const int z0 = n_comp + wave * nz / 8, z1 = n_comp + (wave + 1) * nz / 8;
+    auto fetch = [&](int it, float (&pv)[16]) {
+        const int pair = __builtin_amdgcn_readfirstlane(items[it]);
+        const int s_ = pair >> 3, kb = pair & 7;
+        const int q = s_ * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        const int off0 = qc, off4 = qc + 4 * lh * a.tp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ku = kb * 32 + (r & 3) + 8 * (r >> 2);
+            const float* row = pz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.tp;
+            pv[r] = row[ku + 4 < a.Tk ? off4 : off0];
+        }
+    };
+    int cur_s = -1;
+    float gv[HS];
+    float D = 0.f;
+    auto compute = [&](int it, const float (&pv)[16]) {
+        const int pair = __builtin_amdgcn_readfirstlane(items[it]);
+        const int s_ = pair >> 3, kb = pair & 7;
+        const int q = s_ * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        const int off0 = qc, off4 = qc + 4 * lh * a.tp;
+        if (s_ != cur_s) {   // (wave-uniform) a new strip: its dctx rows and D
+            cur_s = s_;
+            const float* gp = a.dctx + qbase + (long)qc * a.d + lh * HS;
+#pragma unroll
+            for (int s = 0; s < HS; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(gp + s);
+                gv[s] = t.x; gv[s + 1] = t.y; gv[s + 2] = t.z; gv[s + 3] = t.w;
+            }
+            D = Dq[qc];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* vrow = Vs + (kb * 32 + l31) * LD + lh * HS;
+        constexpr int VC = HS < 8 ? HS : 8;
+#pragma unroll
+        for (int s0 = 0; s0 < HS; s0 += VC) {
+            float vr[VC];
+#pragma unroll
+            for (int s = 0; s < VC; s += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(vrow + s0 + s);
+                vr[s] = t.x; vr[s + 1] = t.y; vr[s + 2] = t.z; vr[s + 3] = t.w;
+            }
+#pragma unroll
+            for (int s = 0; s < VC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[s], gv[s0 + s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ku = kb * 32 + (r & 3) + 8 * (r >> 2);
+            const bool both = ku + 4 < a.Tk;
+            const bool mine = both || (lh == 0 && ku < a.Tk);
+            float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.tp;
+            if (mine && q < a.T) row[both ? off4 : off0] = pv[r] * (acc[r] - D) * a.scale;
+        }
+    };
+    float pvA[16], pvB[16];
+    if (c0 < c1) fetch(c0, pvA);
+    for (int it = c0; it < c1; it += 2) {
+        if (it + 1 < c1) fetch(it + 1, pvB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(it, pvA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < c1) {
+            if (it + 2 < c1) fetch(it + 2, pvA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(it + 1, pvB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (int it = z0; it < z1; ++it) {   // nothing but zeros above the diagonal
+        const int pair = __builtin_amdgcn_readfirstlane(items[it]);
+        const int s_ = pair >> 3, kb = pair & 7;
+        const int q = s_ * 32 + l31;
+        const int qc = q < a.T ? q : a.T - 1;
+        const int off0 = qc, off4 = qc + 4 * lh * a.tp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ku = kb * 32 + (r & 3) + 8 * (r >> 2);
+            const bool both = ku + 4 < a.Tk;
+            const bool mine = both || (lh == 0 && ku < a.Tk);
+            float* row = dz + (long)(ku < a.Tk ? ku : a.Tk - 1) * a.tp;
+            if (mine && q < a.T) row[both ? off4 : off0] = 0.f;
+        }
+    }
+}
+
+template <int DH>
+int launch_attn_ds_causal(const AttnDsK& k, long Z, hipStream_t st) {
+    const int nb = (k.Tk + 31) / 32, strips = (k.T + 31) / 32;
+    const size_t shm = (size_t)(32 * nb * (DH + 4) + 32 * strips) * sizeof(float) + 80 * sizeof(int);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_ds_causal_kernel<DH>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    AS_REQUIRE(attr == hipSuccess, (int)attr, "as_attention_bwd_ds: cannot reserve LDS: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((attn_ds_causal_kernel<DH>), dim3((unsigned)Z), dim3(ATT_THREADS), shm, st, k);
     return 0;
 }
 
@@ -376,7 +543,7 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void attn_softmax_bwd_t_kernel(const float* __restrict__ pt, float* __restrict__ dpt,
-                                                                 const float* __restrict__ D, long total4, int T, long plane,
+                                                                 const float* __restrict__ D, long total4, int T, int Tp, long plane,
                                                                  float scale) {
     const long stride = (long)gridDim.x * 256;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total4; i0 += 4 * stride) {  // four float4 pairs in flight
@@ -391,9 +558,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_t_kernel(const float* __
         for (int u = 0; u < 4; ++u) {
             const long i = i0 + u * stride;
             if (i < total4) {
-                const long e = 4 * i;                     // T % 4 == 0: the float4 is q .. q + 3 of one key row
+                const long e = 4 * i;                     // T % 4 == 0: the float4 is q .. q + 3 of one key row (row pitch Tp)
                 const long z = e / plane;
-                const int q = (int)((e - z * plane) % T);
+                const int q = (int)((e - z * plane) % Tp);
+                if (q >= T) continue;                     // the row's padding up to the pitch
                 const float4 dq = *reinterpret_cast<const float4*>(D + z * T + q);
                 float4 r;
                 r.x = pv[u].x * (dv[u].x - dq.x) * scale;
@@ -407,13 +575,13 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_t_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void attn_softmax_bwd_t_scalar_kernel(const float* __restrict__ pt, float* __restrict__ dpt,
-                                                                        const float* __restrict__ D, long total, int T, long plane,
+                                                                        const float* __restrict__ D, long total, int T, int Tp, long plane,
                                                                         float scale) {
     const long stride = (long)gridDim.x * 256;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
         const long z = e / plane;
-        const int q = (int)((e - z * plane) % T);
-        dpt[e] = pt[e] * (dpt[e] - D[z * T + q]) * scale;
+        const int q = (int)((e - z * plane) % Tp);
+        if (q < T) dpt[e] = pt[e] * (dpt[e] - D[z * T + q]) * scale;
     }
 }
 
@@ -457,6 +625,7 @@ extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, 
     AttnK k;
     k.Q = Q; k.K = K; k.V = V; k.O = out; k.mask_t = attn_mask_t; k.kpm = key_padding_mask; k.lse = lse; k.probs_t = probs_t;
     k.B = B; k.heads = heads; k.T = T; k.Tk = Tk; k.d = d; k.scale = scale;
+    k.tp = (T + 31) / 32 * 32;
     const long Z = (long)G * B * heads;
     hipStream_t st = (hipStream_t)stream;
     const int dh = d / heads;
@@ -480,24 +649,25 @@ extern "C" int as_attn_softmax_bwd_t(const float* probs_t, float* dprobs_t, cons
     const long lanes = rows * heads * (dh / 4);
     hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)as_cdiv(lanes, 256)), dim3(256), 0, st, ctx, dctx, rows, heads, T, B, d, dsum);
     AS_LAUNCH_CHECK("as_attn_softmax_bwd_t(dsum)");
-    const long plane = (long)Tk * T, total = Z * plane;
+    const int Tp = (T + 31) / 32 * 32;   // row pitch of the key-major tensors (as_attention_fwd)
+    const long plane = (long)Tk * Tp, total = Z * plane;
     const bool vec = T % 4 == 0 && ((reinterpret_cast<uintptr_t>(probs_t) | reinterpret_cast<uintptr_t>(dprobs_t) |
                                      reinterpret_cast<uintptr_t>(dsum)) & 15) == 0;
     if (vec) {
         long blocks = as_cdiv(total / 4, 4 * 256);
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(attn_softmax_bwd_t_kernel, dim3((unsigned)blocks), dim3(256), 0, st, probs_t, dprobs_t, dsum, total / 4, T, plane, scale);
+        hipLaunchKernelGGL(attn_softmax_bwd_t_kernel, dim3((unsigned)blocks), dim3(256), 0, st, probs_t, dprobs_t, dsum, total / 4, T, Tp, plane, scale);
     } else {
         long blocks = as_cdiv(total, 256);
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(attn_softmax_bwd_t_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, probs_t, dprobs_t, dsum, total, T, plane, scale);
+        hipLaunchKernelGGL(attn_softmax_bwd_t_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, probs_t, dprobs_t, dsum, total, T, Tp, plane, scale);
     }
     AS_LAUNCH_CHECK("as_attn_softmax_bwd_t");
     return 0;
 }
 
-extern "C" int as_attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G,
-                                   int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream) {
+static int attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G,
+                            int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, int causal, void* stream) {
     AS_REQUIRE(V && dctx && ctx && probs_t && ds_t && G > 0 && B > 0 && heads > 0 && T > 0 && Tk > 0 && d > 0, AS_ERR_BAD_ARG,
                "as_attention_bwd_ds: bad argument");
     AS_REQUIRE(as_attention_supported(T, Tk, d, heads), AS_ERR_UNSUPPORTED,
@@ -507,12 +677,28 @@ extern "C" int as_attention_bwd_ds(const float* V, const float* dctx, const floa
     AttnDsK k;
     k.V = V; k.dctx = dctx; k.ctx = ctx; k.probs_t = probs_t; k.ds_t = ds_t;
     k.B = B; k.heads = heads; k.T = T; k.Tk = Tk; k.d = d; k.scale = scale;
+    k.tp = (T + 31) / 32 * 32;
     const long Z = (long)G * B * heads;
     hipStream_t st = (hipStream_t)stream;
     const int dh = d / heads;
-    if (dh == 64) AS_TRY(launch_attn_ds_nb<64>(k, Z, st));
+    if (causal && T <= 256 && Tk <= 256) {
+        if (dh == 64) AS_TRY(launch_attn_ds_causal<64>(k, Z, st));
+        else if (dh == 32) AS_TRY(launch_attn_ds_causal<32>(k, Z, st));
+        else AS_TRY(launch_attn_ds_causal<16>(k, Z, st));
+    } else if (dh == 64) AS_TRY(launch_attn_ds_nb<64>(k, Z, st));
     else if (dh == 32) AS_TRY(launch_attn_ds_nb<32>(k, Z, st));
     else AS_TRY(launch_attn_ds_nb<16>(k, Z, st));
     AS_LAUNCH_CHECK("as_attention_bwd_ds");
     return 0;
+}
+
+extern "C" int as_attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G,
+                                   int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream) {
+    return attention_bwd_ds(V, dctx, ctx, probs_t, ds_t, G, B, heads, T, Tk, d, scale, 0, stream);
+}
+
+extern "C" int as_attention_bwd_ds_causal(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t,
+                                          int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale,
+                                          void* stream) {
+    return attention_bwd_ds(V, dctx, ctx, probs_t, ds_t, G, B, heads, T, Tk, d, scale, 1, stream);
 }

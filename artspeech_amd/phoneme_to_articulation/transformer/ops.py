@@ -292,7 +292,11 @@ def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
     if FUSED_ATTENTION and L.as_attention_supported(T, Tk, d, heads):
         # scores stay in registers (as_attention_fwd); training additionally keeps the probabilities, key-major
         out = torch.empty_like(Q)
-        Pt = torch.empty((Z, Tk, T), dtype=torch.float32, device=dev) if training else None
+        # key-major probabilities with rows padded to a multiple of 32 floats: a strip's 128-byte segment of a row is then one
+        # cache line for the forward's stores, the dS kernel and the backward GEMMs (at T = 200 the natural 800-byte pitch
+        # makes every segment straddle two)
+        Tp = (T + 31) // 32 * 32
+        Pt = torch.empty((Z, Tk, Tp), dtype=torch.float32, device=dev) if training else None
         mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
         _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
                                       _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
@@ -324,27 +328,30 @@ def attention_backward(saved, B, heads, scale, dctx, dQ=None, dK=None, dV=None, 
     dV = torch.empty_like(V) if dV is None else dV
     if len(saved) == 5:
         # backward of the fused forward: the same five products as the unfused path, on the KEY-major probabilities
-        # P^T [Z][Tk][T] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
+        # P^T [Z][Tk][Tp] that as_attention_fwd left (only the operand strides differ), D = rowsum(dctx * ctx) instead of a
         # second pass over the scores
         Pt, out = saved[3:]
         dPt = torch.empty_like(Pt)
+        Tp = Pt.shape[2]   # row pitch of the key-major tensors: T rounded up to 32 (attention_forward)
+        zp = _table(dev, ("zp", Z, Tk, Tp), lambda: [z * Tk * Tp for z in range(Z)])
         # causal mask: P^T[key][q] and dS^T[key][q] are exact zeros for q < key -- the three products below skip those k-tiles
         lower = dict(k_tri=1, precision=0) if causal else {}   # reduction over q, rows = keys: zero for q < key
         upper = dict(k_tri=2, precision=0) if causal else {}   # reduction over keys, rows = q: zero for key > q
         # dV = P^T dctx
-        _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk, **lower)
+        _gemm(A=Pt, B=dctx, C=dV, M=Tk, N=dh, K=T, a_i=Tp, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zp, b_off=zq, c_off=zk, **lower)
         if FUSED_DS:
             # dS^T = P^T o (V dctx^T - D) * scale in one kernel: dP is never formed
-            _lib.check(_lib.lib().as_attention_bwd_ds(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T,
-                                                      Tk, d, scale, _lib.stream_ptr()), "as_attention_bwd_ds")
+            ds_fn = _lib.lib().as_attention_bwd_ds_causal if causal else _lib.lib().as_attention_bwd_ds
+            _lib.check(ds_fn(_lib.ptr(V), _lib.ptr(dctx), _lib.ptr(out), _lib.ptr(Pt), _lib.ptr(dPt), G, B, heads, T, Tk, d, scale,
+                             _lib.stream_ptr()), "as_attention_bwd_ds")
         else:
-            _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=T, batch=Z, a_off=zk, b_off=zq, c_off=zs)
+            _gemm(A=V, B=dctx, C=dPt, M=Tk, N=T, K=dh, a_i=d, a_k=1, b_j=d, b_k=1, ldc=Tp, batch=Z, a_off=zk, b_off=zq, c_off=zp)
             dsum = torch.empty((Z, T), dtype=torch.float32, device=dev)
             _lib.check(_lib.lib().as_attn_softmax_bwd_t(_lib.ptr(Pt), _lib.ptr(dPt), _lib.ptr(out), _lib.ptr(dctx), _lib.ptr(dsum), G, B,
                                                         heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attn_softmax_bwd_t")
         # dQ = dS K (dS read through its transpose) ; dK = dS^T Q
-        _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=T, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zk, c_off=zq, **upper)
-        _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=T, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zs, b_off=zq, c_off=zk, **lower)
+        _gemm(A=dPt, B=K, C=dQ, M=T, N=dh, K=Tk, a_i=1, a_k=Tp, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zp, b_off=zk, c_off=zq, **upper)
+        _gemm(A=dPt, B=Q, C=dK, M=Tk, N=dh, K=T, a_i=Tp, a_k=1, b_j=1, b_k=d, ldc=d, batch=Z, a_off=zp, b_off=zq, c_off=zk, **lower)
         return dQ, dK, dV
     P = saved[3]
     dP = torch.empty_like(P)

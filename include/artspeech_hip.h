@@ -358,8 +358,10 @@ int as_attn_softmax_bwd(const float* probs, float* dprobs, int64_t Z, int32_t Tq
  *                      the key dimension padded to Tk32 = Tk rounded up to a multiple of 32 (finite padding), or NULL
  *   key_padding_mask : [B][Tk] additive float mask (0 / -inf) or NULL
  *   lse              : optional [G*B*heads][T] log-sum-exp of every score row (what a recomputing backward needs), or NULL
- *   probs_t          : optional [G*B*heads][Tk][T] the probabilities, KEY-major (training: consumed by the grouped GEMMs of
- *                      the backward and by as_attn_softmax_bwd_t), or NULL (inference: nothing but `out` is written)
+ *   probs_t          : optional [G*B*heads][Tk][Tp] the probabilities, KEY-major, rows padded to Tp = T rounded up to a multiple
+ *                      of 32 floats (columns >= T are not written; a 32-query segment of a row is then one 128-byte line)
+ *                      (training: consumed by the grouped GEMMs of the backward and by as_attn_softmax_bwd_t), or NULL
+ *                      (inference: nothing but `out` is written)
  * Scores and probabilities stay in registers (the unfused path writes G*B*heads*T*Tk floats twice).  A fully masked query
  * row yields NaN, as in PyTorch. */
 int as_attention_supported(int32_t T, int32_t Tk, int32_t d, int32_t heads);
@@ -369,17 +371,23 @@ int as_attention_fwd(const float* Q, const float* K, const float* V, const float
 
 /* Softmax backward on KEY-major tensors, in place on dprobs_t:  dS^T[k][q] = P^T[k][q] * (dP^T[k][q] - D[q]) * scale with
  * D[q] = sum_c dctx[q][c] * ctx[q][c] over the head's dh columns (= sum_k P dP, without a second pass over the scores).
- *   probs_t, dprobs_t : [G*B*heads][Tk][T]        ctx, dctx : [G][B*T][d] (attention output and its gradient)
+ *   probs_t, dprobs_t : [G*B*heads][Tk][Tp], Tp = T rounded up to 32      ctx, dctx : [G][B*T][d] (attention output and its gradient)
  *   dsum              : workspace of G*B*heads*T floats (receives D); dh = d / heads in {16, 32, 64} */
 int as_attn_softmax_bwd_t(const float* probs_t, float* dprobs_t, const float* ctx, const float* dctx, float* dsum, int32_t G,
                           int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream);
 
 /* Backward of the attention core, first half, without a dP tensor:
  *   ds_t[z][k][q] = probs_t[z][k][q] * (sum_c V_h[k][c] dctx[q][h*dh + c] - D[q]) * scale,   D[q] = sum_c dctx[q][c] ctx[q][c]
- * (= as_attn_softmax_bwd_t applied to dP^T = V dctx^T).  Shapes as as_attention_fwd; ds_t [G*B*heads][Tk][T] is what the
+ * (= as_attn_softmax_bwd_t applied to dP^T = V dctx^T).  Shapes as as_attention_fwd; ds_t [G*B*heads][Tk][Tp] is what the
  * two remaining grouped GEMMs (dQ = dS K, dK = dS^T Q) read. */
 int as_attention_bwd_ds(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G, int32_t B,
                         int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream);
+/* The same when the forward's additive mask was -inf above the diagonal for every utterance (both decoder masks of
+ * transformer/models.py:380-387 are causal), i.e. probs_t[z][key][q] == 0 for q < key: only the (32-query strip, 32-key block)
+ * pairs on or below the diagonal are computed -- dealt evenly over the workgroup's waves -- the others are stored as zeros.  Same
+ * values as as_attention_bwd_ds where P^T is non-zero; exact +0 elsewhere.  T, Tk <= 256 (else the general kernel runs). */
+int as_attention_bwd_ds_causal(const float* V, const float* dctx, const float* ctx, const float* probs_t, float* ds_t, int32_t G,
+                               int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream);
 
 /* dst[c][:] = sum over groups g with src[g] == c of part[g][:] (rows of `len` floats; deterministic order): folds
  * the per-block input gradients of a grouped GEMM back onto the channels the blocks read. */
