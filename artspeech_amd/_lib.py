@@ -95,6 +95,7 @@ PROTOTYPES = {
     "as_attn_softmax_bwd": (_I32, [_P, _P, _I64, _I32, _I32, _F, _P]),
     "as_attention_supported": (_I32, [_I32, _I32, _I32, _I32]),
     "as_attention_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "as_attention_fwd_causal": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "as_attention_bwd_ds": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "as_attention_bwd_ds_causal": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "as_attn_softmax_bwd_t": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),

@@ -31,6 +31,7 @@ struct AttnK {
     float* lse;           // [Z][T] row maximum + log of the row sum (for a backward that recomputes P) or nullptr
     float* probs_t;       // [Z][Tk][tp] the probabilities, KEY-major (what the unfused backward consumes), or nullptr
     int B, heads, T, Tk, d;
+    int causal;           // the mask is -inf above the diagonal for every utterance: key blocks beyond a strip's own are skipped
     int tp;               // row pitch of probs_t: T rounded up to 32 floats, so that a strip's 128-byte row segment is one cache line
                           // (at the natural pitch of T = 200 floats = 800 B every segment straddles two lines)
     float scale;
@@ -77,9 +78,20 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
     const float* vl = Vs + 4 * lh * LD + l31;  // this lane's corner of V^T: row 4 lh (+ key_r), column l31 (+ 32 ob)
     const float* kpl = kp + 4 * lh;
     const int strips = (a.T + 31) / 32;
-    for (int strip = wave; strip < strips; strip += ATT_THREADS / 64) {
+    // Causal mask: strip s only has the key blocks 0 .. s (the others hold exact zeros: no MFMAs, no mask loads for them), so
+    // the strips cost 1 .. strips blocks.  Waves w and w + 4 share a SIMD: the strips are dealt so that every SIMD gets about
+    // the same number of blocks (at 7 strips: {6,0} {5,1} {4,2} {3} = 8, 8, 8, 4 blocks instead of 14 each).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool balanced = a.causal && strips <= ATT_THREADS / 64;
+    for (int it = wave_u; it < (balanced ? ATT_THREADS / 64 : strips); it += ATT_THREADS / 64) {
+        int strip = it;
+        if (balanced) {   // waves 0-3: the four longest strips, descending; waves 4-7: the short ones, ascending; one strip per wave
+            strip = it < 4 ? strips - 1 - it : (it - 4 <= strips - 5 ? it - 4 : -1);
+            if (strip < 0) break;
+        }
         const int q = strip * 32 + l31;
         const int qc = q < a.T ? q : a.T - 1;
+        const int last_blk = a.causal ? min(strip, NB - 1) : NB - 1;   // (wave-uniform) the last key block that holds anything
         // the lane's query row, the half of it this half-wave feeds to the MFMA: columns lh*HS + s
         float qv[HS];
         {
@@ -93,6 +105,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
         f32x16 sacc[NB];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
+            if (blk > last_blk) {   // masked for every query of the strip: the scores are -inf, the probabilities exact zeros
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[blk][r] = -INFINITY;
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
             float kv[HS];
@@ -116,9 +133,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
             const int moff = qc + 4 * lh * a.T;
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {  // 16 loads in flight per block (all NB x 16 at once would not fit the registers)
+                if (blk > last_blk) continue;
                 float mv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = (mt + (long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * a.T)[moff];
+                for (int r = 0; r < 16; ++r) {
+                    int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                    asm volatile("" : "+s"(ku));   // (row pointers recomputed on the scalar unit, not hoisted into ~200 SGPRs)
+                    mv[r] = (mt + (long)ku * a.T)[moff];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[blk][r] = sacc[blk][r] * a.scale + mv[r];
                 __builtin_amdgcn_sched_barrier(0);
@@ -163,6 +185,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
             for (int r = 0; r < 16; ++r) oacc[ob][r] = 0.f;
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
+            if (blk > last_blk) {   // zeros (NaN for a query whose whole row is masked, as everywhere else in that row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[blk][r] *= inv;
+                continue;
+            }
             float vv[16][OB];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -187,7 +214,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnK a) {
             for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                    int ku = blk * 32 + (r & 3) + 8 * (r >> 2);
+                    asm volatile("" : "+s"(ku));
                     if (q < a.T && ku + 4 * lh < a.Tk) (pz + (long)ku * a.tp)[poff] = sacc[blk][r];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -614,9 +642,9 @@ extern "C" int as_attention_supported(int32_t T, int32_t Tk, int32_t d, int32_t 
     return (dh == 16 || dh == 32 || dh == 64) && Tk <= 256;
 }
 
-extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
-                                float* out, float* lse, float* probs_t, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d,
-                                float scale, void* stream) {
+static int attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
+                         float* out, float* lse, float* probs_t, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d,
+                         float scale, int causal, void* stream) {
     AS_REQUIRE(Q && K && V && out && G > 0 && B > 0 && heads > 0 && T > 0 && Tk > 0 && d > 0, AS_ERR_BAD_ARG, "as_attention_fwd: bad argument");
     AS_REQUIRE(as_attention_supported(T, Tk, d, heads), AS_ERR_UNSUPPORTED,
                "as_attention_fwd: head width %d / %d not in {16, 32, 64} or Tk=%d > 256 (use the unfused path)", d, heads, Tk);
@@ -626,6 +654,7 @@ extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, 
     k.Q = Q; k.K = K; k.V = V; k.O = out; k.mask_t = attn_mask_t; k.kpm = key_padding_mask; k.lse = lse; k.probs_t = probs_t;
     k.B = B; k.heads = heads; k.T = T; k.Tk = Tk; k.d = d; k.scale = scale;
     k.tp = (T + 31) / 32 * 32;
+    k.causal = causal && attn_mask_t != nullptr;
     const long Z = (long)G * B * heads;
     hipStream_t st = (hipStream_t)stream;
     const int dh = d / heads;
@@ -634,6 +663,18 @@ extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, 
     else AS_TRY(launch_attn_nb<16>(k, Z, st));
     AS_LAUNCH_CHECK("as_attention_fwd");
     return 0;
+}
+
+extern "C" int as_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
+                                float* out, float* lse, float* probs_t, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d,
+                                float scale, void* stream) {
+    return attention_fwd(Q, K, V, attn_mask_t, key_padding_mask, out, lse, probs_t, G, B, heads, T, Tk, d, scale, 0, stream);
+}
+
+extern "C" int as_attention_fwd_causal(const float* Q, const float* K, const float* V, const float* attn_mask_t,
+                                       const float* key_padding_mask, float* out, float* lse, float* probs_t, int32_t G, int32_t B,
+                                       int32_t heads, int32_t T, int32_t Tk, int32_t d, float scale, void* stream) {
+    return attention_fwd(Q, K, V, attn_mask_t, key_padding_mask, out, lse, probs_t, G, B, heads, T, Tk, d, scale, 1, stream);
 }
 
 extern "C" int as_attn_softmax_bwd_t(const float* probs_t, float* dprobs_t, const float* ctx, const float* dctx, float* dsum, int32_t G,

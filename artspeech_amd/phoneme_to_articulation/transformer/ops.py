@@ -298,9 +298,10 @@ def attention_forward(Q, K, V, attn_mask, kpm, B, heads, training):
         Tp = (T + 31) // 32 * 32
         Pt = torch.empty((Z, Tk, Tp), dtype=torch.float32, device=dev) if training else None
         mt = _key_major_mask(attn_mask, Tk, T) if attn_mask is not None else None
-        _lib.check(L.as_attention_fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None,
-                                      _lib.ptr(Pt), G, B, heads, T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
         causal = mt is not None and bool(getattr(mt, "causal", False))
+        fwd = L.as_attention_fwd_causal if causal else L.as_attention_fwd
+        _lib.check(fwd(_lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(mt), _lib.ptr(km), _lib.ptr(out), None, _lib.ptr(Pt), G, B, heads,
+                       T, Tk, d, scale, _lib.stream_ptr()), "as_attention_fwd")
         return out, ((Q, K, V, Pt, out) if training else None), scale, causal
     zq, zk, zs = _z_tables(dev, G, B, T, Tk, d, heads)
     P = torch.empty((Z, T, Tk), dtype=torch.float32, device=dev)

@@ -368,6 +368,13 @@ int as_attention_supported(int32_t T, int32_t Tk, int32_t d, int32_t heads);
 int as_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
                      float* out, float* lse, float* probs_t, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk, int32_t d,
                      float scale, void* stream);
+/* The same for a mask the CALLER has checked to be -inf above the diagonal for every utterance (attn_mask[b][q][k] == -inf for
+ * k > q: both decoder masks of transformer/models.py:380-387): the key blocks beyond a 32-query strip's own are not computed
+ * (their probabilities are exact zeros either way) and the strips are dealt over the waves so that every SIMD gets the same
+ * number of blocks.  Identical results. */
+int as_attention_fwd_causal(const float* Q, const float* K, const float* V, const float* attn_mask_t, const float* key_padding_mask,
+                            float* out, float* lse, float* probs_t, int32_t G, int32_t B, int32_t heads, int32_t T, int32_t Tk,
+                            int32_t d, float scale, void* stream);
 
 /* Softmax backward on KEY-major tensors, in place on dprobs_t:  dS^T[k][q] = P^T[k][q] * (dP^T[k][q] - D[q]) * scale with
  * D[q] = sum_c dctx[q][c] * ctx[q][c] over the head's dh columns (= sum_k P dP, without a second pass over the scores).
