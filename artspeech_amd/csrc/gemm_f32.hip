@@ -43,8 +43,10 @@ struct GemmK {
     const unsigned* mask_bits; long mask_batch;
     unsigned* relu_bits; long relu_bits_batch;
     // optional segmented reduction (as_gemm.k_seg): per (batch, segment) element offsets of the A rows and the B panel
-    int k_seg; const long* a_seg_off; const long* b_seg_off;
+    int k_seg;
     int k_tri;   // as_gemm.k_tri: the A operand is exactly zero for k < i (1) or k > i (2): a tile's reduction range shrinks
+                 // (kept in k_seg's padding: a larger kernel-argument block measurably slows the BiGRU step's 64 x 64 launches)
+    const long* a_seg_off; const long* b_seg_off;
 };
 
 // device-scope accesses for data handed between workgroups of one launch (they may sit on different XCDs, whose L2s are not
@@ -200,13 +202,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         const int xy = wrem - x.ks * per_split;
         x.xy = xy;
         x.tn_idx = xy / tiles_m;
-        int tm = xy - x.tn_idx * tiles_m;
-        // triangular A: an M-tile's reduction length depends on its position, and a workgroup that strides the work list by a
-        // multiple of the tiles per batch member would always get the same position (the longest one sets the launch time):
-        // rotate the M-tile by the round, so that every workgroup sees every length.  (A bijection on a batch member's tiles
-        // as long as they all sit in one round: grid % tiles per batch member == 0, else no rotation.)
-        if (g.k_tri != 0 && tiles_n == 1 && g.splitk == 1 && gridDim.x % tiles_m == 0) tm = (tm + (int)(w / gridDim.x)) % tiles_m;
-        x.m0 = tm * BM;
+        if constexpr (EXT) {
+            int tm = xy - x.tn_idx * tiles_m;
+            // triangular A: an M-tile's reduction length depends on its position, and a workgroup that strides the work list by
+            // a multiple of the tiles per batch member would always get the same position (the longest one sets the launch
+            // time): rotate the M-tile by the round, so that every workgroup sees every length.  (A bijection on a batch
+            // member's tiles as long as they all sit in one round: grid % tiles per batch member == 0, else no rotation.)
+            if (g.k_tri != 0 && tiles_n == 1 && g.splitk == 1 && gridDim.x % tiles_m == 0) tm = (tm + (int)(w / gridDim.x)) % tiles_m;
+            x.m0 = tm * BM;
+        } else {
+            x.m0 = (xy - x.tn_idx * tiles_m) * BM;
+        }
         x.n0 = x.tn_idx * BN;
         x.A = g.A + (g.a_off ? g.a_off[x.bz] : (long)x.bz * g.a_batch);
         x.B = g.B + (g.b_off ? g.b_off[x.bz] : (long)x.bz * g.b_batch);
@@ -215,8 +221,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         x.kend = min(g.K, x.kbeg + g.kchunk);
         // triangular A (causal attention probabilities and their gradients): the k-tiles in which every row of this tile is zero
         // are not visited -- the skipped products are exact zeros
-        if (g.k_tri == 1) x.kbeg = max(x.kbeg, (x.m0 / BK) * BK);
-        else if (g.k_tri == 2) x.kend = min(x.kend, ((x.m0 + BM + BK - 1) / BK) * BK);
+        // (extended instantiation only: in the plain one the few extra scalar instructions per tile cost the BiGRU step's short
+        // 64 x 64 launches 8-13 %)
+        if constexpr (EXT) {
+            if (g.k_tri == 1) x.kbeg = max(x.kbeg, (x.m0 / BK) * BK);
+            else if (g.k_tri == 2) x.kend = min(x.kend, ((x.m0 + BM + BK - 1) / BK) * BK);
+        }
         x.kshift = g.b_kshift + x.bz * g.b_kshift_batch;
         return x;
     };
@@ -734,16 +744,18 @@ int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
         const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);            \
     } while (0)
-    if (k.res || k.mask_bits || k.relu_bits || k.k_seg > 0) {   // the extended instantiations (as_gemm_f32 has checked a_kc and float4-clean operands)
-#define AS_GEMM_LAUNCH_EXT(BK_)                                                                      \
-    do {                                                                                             \
-        static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, true, BK_, true, true>);    \
-        const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, BK_, true, true>), grid, block, 0, st, k); \
+    if (k.res || k.mask_bits || k.relu_bits || k.k_seg > 0 || k.k_tri != 0) {   // the extended instantiations (operands checked by as_gemm_f32)
+#define AS_GEMM_LAUNCH_EXT(AK, BK_)                                                                    \
+    do {                                                                                               \
+        static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, AK, BK_, true, true>);        \
+        const dim3 grid((unsigned)(work < slots ? work : slots));                                      \
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, true, true>), grid, block, 0, st, k);     \
     } while (0)
         if constexpr (BM == BN) {   // 128 x 128 and 64 x 64 only
-            if (b_kc) AS_GEMM_LAUNCH_EXT(true);
-            else AS_GEMM_LAUNCH_EXT(false);
+            if (a_kc && b_kc) AS_GEMM_LAUNCH_EXT(true, true);
+            else if (a_kc) AS_GEMM_LAUNCH_EXT(true, false);
+            else if (!b_kc) AS_GEMM_LAUNCH_EXT(false, false);   // (k_tri = 2: dQ = dS K reads dS^T through its transpose)
+            else AS_REQUIRE(false, AS_ERR_BAD_ARG, "as_gemm_f32: the extended operands have no kernel for a strided A with a contiguous B");
         } else {
             AS_REQUIRE(false, AS_ERR_BAD_ARG, "as_gemm_f32: the extended operands need a square tile");
         }
@@ -802,8 +814,15 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.k_seg = g->k_seg; k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
     k.k_tri = g->k_tri;
     AS_REQUIRE(g->k_tri >= 0 && g->k_tri <= 2, AS_ERR_BAD_ARG, "as_gemm_f32: k_tri=%d", g->k_tri);
-    AS_REQUIRE(g->k_tri == 0 || (!g->colsum && !g->splitk_ws && g->precision == 0 && g->k_seg == 0), AS_ERR_BAD_ARG,
-               "as_gemm_f32: k_tri goes with the general kernel only (no colsum, splitk_ws, split precision or k_seg)");
+    AS_REQUIRE(g->k_tri == 0 || (!g->colsum && !g->splitk_ws && g->precision == 0 && g->k_seg == 0 && !g->accumulate && g->act <= 1 &&
+                                 !g->bias_off && (long)g->M * g->ldc < (1L << 31)),
+               AS_ERR_BAD_ARG, "as_gemm_f32: k_tri goes with the extended general kernel only (no colsum, splitk_ws, split precision, "
+               "k_seg, accumulate, act > 1)");
+    // k_tri is a hint about zeros: operands the extended (float4) instantiation cannot take run the plain kernel over the full range
+    if (g->k_tri != 0 && !(aligned16(g->A) && aligned16(g->B) && a_ld % 4 == 0 && b_ld % 4 == 0 && (a_kc ? g->K % 4 == 0 : g->M % 4 == 0) &&
+                           (b_kc ? g->K % 4 == 0 : g->N % 4 == 0) && (g->a_off || g->a_batch % 4 == 0) && (g->b_off || g->b_batch % 4 == 0) &&
+                           (a_kc || !b_kc)))
+        k.k_tri = 0;
     const bool epi_ops = g->res || g->mask_bits || g->relu_bits, segmented = g->k_seg > 0;
     AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && g->precision == 0 && (a_kc || b_kc)),
                AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg go with the general kernel only (no colsum, splitk_ws, "

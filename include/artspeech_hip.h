@@ -245,7 +245,8 @@ typedef struct as_gemm {
        counted in the same index space -- the key-major probabilities P^T[key][q] of a causally masked attention and their
        gradients (transformer/models.py:380-387: both decoder masks are causal).  An output tile then only walks the k-tiles
        in which one of its rows can be non-zero; the skipped products are exact zeros (a non-finite B element in a skipped
-       range no longer turns 0 * inf into NaN).  General kernel only, like k_seg. */
+       range no longer turns 0 * inf into NaN).  General kernel only, like k_seg; a HINT: operands that are not float4-clean
+       (16-byte aligned, strides and contiguous extents multiples of 4) are multiplied over the full range, same result. */
     int32_t k_tri;
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
