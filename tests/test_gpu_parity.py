@@ -4,13 +4,14 @@ the same seeded inputs and against the committed golden fixtures (outputs of the
 Tolerances (north-star): contour coordinates within 1e-4 relative (fp32); arg-min indices bit-exact.
 Run with ``pytest -m gpu`` on an MI355X.
 """
+import os
 import ctypes as C
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import assert_grad_close, load_golden, split_wg
+from conftest import assert_grad_close, load_golden, oracle_gradients_with_the_devices_relu_decisions, split_wg
 from oracle import artspeech_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -763,6 +764,55 @@ def test_artspeech_other_hidden_sizes_vs_oracle(dev, H):
     assert torch.equal(out2, out.detach())
 
 
+def _random_configuration(seed):
+    r = np.random.RandomState(1000 + seed)
+    cfg = dict(V=int(r.randint(2, 130)), A=int(r.randint(1, 13)), E=int(r.choice([1, 5, 8, 13, 24, 30, 64, 100])),
+               H=int(r.choice([32, 64, 128, 128, 20, 44, 72])), N=int(r.choice([1, 3, 10, 25, 33, 50, 50, 64, 70])),
+               B=int(r.randint(1, 10)), T=int(r.randint(1, 75)))
+    lengths = np.sort(r.randint(1, cfg["T"] + 1, cfg["B"]))[::-1].copy()
+    if seed % 3 == 0:
+        lengths[:] = lengths[0]          # no padding at all
+    cfg["lengths"] = lengths
+    cfg["T"] = int(lengths[0])           # the reference's batches are padded to their longest utterance
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AS_FUZZ_SEEDS", "12"))))   # (a wider sweep: AS_FUZZ_SEEDS=150)
+def test_artspeech_random_configurations_vs_oracle(dev, seed):
+    """Seeded random architectures and batch shapes (vocabulary 2-129, 1-12 articulators, odd embedding widths, hidden sizes on
+    both recurrence families, 1-70 samples per contour, 1-9 utterances of 1-74 frames, ragged or not): contours, loss and every
+    parameter gradient against the oracle at the usual element-wise bound.  The reference accepts all of them
+    (encoder_decoder/models.py:100-145).  Where the oracle's ReLU input lies within 5e-6 of zero the device's fp32 decision
+    may differ from the fp64 one (conftest.oracle_gradients_with_the_devices_relu_decisions); nothing else is loosened."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    c = _random_configuration(seed)
+    V, A, N, B, T, lengths = c["V"], c["A"], c["N"], c["B"], c["T"], c["lengths"]
+    torch.manual_seed(seed)
+    model = ArtSpeech(V, A, embed_dim=c["E"], hidden_size=c["H"], n_samples=N)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    rng = np.random.RandomState(seed)
+    x = rng.randint(1, V, (B, T)) if V > 1 else np.zeros((B, T), np.int64)
+    tgt = rng.rand(B, T, A, 2, N).astype(np.float32)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    assert tuple(out.shape) == (B, T, A, 2, N), c
+    loss = masked_euclidean_loss(out, T_(tgt, dev), lengths)
+    loss.backward()
+    o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
+    assert_close(out.detach().cpu().numpy(), o_out, what=f"contours {c}")
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6, c
+    got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
+    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A)
+    assert len(flips) <= 4 and all(abs(z) < 5e-6 for _, _, z in flips), flips
+    for k, v in got.items():
+        assert_grad_close(v, og[k], f"{c} (ReLU decisions taken from the device: {flips}): {k}")
+
+
 # ------------------------------------------------------------------------------------------- metrics
 def test_metrics_match_reference_fixture(dev):
     from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance
@@ -802,6 +852,54 @@ def test_metrics_match_reference_fixture(dev):
         assert np.abs(xs.cpu().numpy() - ox).max() < 1e-5 and np.abs(ys.cpu().numpy() - oy).max() < 1e-5, (b, l)
     with pytest.raises(RuntimeError):
         root.pearsons_correlation(out.detach().cpu(), tgt.cpu())   # no CPU path
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_metric_kernels_random_shapes_vs_oracle(dev, seed):
+    """Seeded random shapes for the criterion and the metrics (metrics.py:5-46, root metrics.py:9-68): 1-13 articulators, 1-130
+    points per contour, unequal point counts for P2CP, contiguous and transposed-view operands, ragged lengths for the masked
+    mean -- against the fp64 oracle."""
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance, masked_euclidean_loss
+    from artspeech_amd import metrics as root
+    r = np.random.RandomState(500 + seed)
+    B, T, A = int(r.randint(1, 6)), int(r.randint(1, 40)), int(r.randint(1, 14))
+    N, M = int(r.choice([1, 2, 7, 25, 26, 50, 63, 64, 65, 100, 130])), int(r.choice([1, 3, 12, 25, 50, 64, 77, 130]))
+    o = r.rand(B, T, A, 2, N).astype(np.float32)
+    g = r.rand(B, T, A, 2, N).astype(np.float32)
+    lengths = np.sort(r.randint(1, T + 1, B))[::-1].copy()
+    lengths[0] = T
+    out = T_(o, dev).requires_grad_(True)
+    tgt = T_(g, dev)
+    w = r.rand(B, T, A, N).astype(np.float32)
+    dist = EuclideanDistance("none")(out, tgt)
+    assert_close(dist.detach().cpu().numpy(), O.euclidean_distance(o.astype(np.float64), g.astype(np.float64)), rtol=1e-6, atol=1e-7,
+                 what="euclid none")
+    (dist * T_(w, dev)).sum().backward()
+    d64 = O.euclidean_distance(o.astype(np.float64), g.astype(np.float64))
+    ref = np.stack([(o[..., 0, :] - g[..., 0, :]) * w / d64, (o[..., 1, :] - g[..., 1, :]) * w / d64], axis=-2)
+    assert_close(out.grad.cpu().numpy(), ref, rtol=2e-5, atol=1e-7, what="euclid grad")
+    out.grad = None
+    loss = masked_euclidean_loss(out, tgt, lengths)
+    loss.backward()
+    o_loss, o_dout = O.masked_euclid_loss(o, g, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    assert_close(out.grad.cpu().numpy(), o_dout, rtol=2e-5, atol=1e-9, what="masked loss grad")
+    # P2CP: same point count through the transposed view of (.., 2, N) storage, unequal counts through contiguous (.., n, 2)
+    p = MeanP2CPDistance("none")(out.detach().transpose(-1, -2), tgt.transpose(-1, -2))
+    assert relmax(p.cpu().numpy(), O.p2cp_distance(o, g)) < 2e-6
+    u, v = r.rand(B, A, N, 2).astype(np.float32), r.rand(B, A, M, 2).astype(np.float32)
+    p = MeanP2CPDistance("none")(T_(u, dev), T_(v, dev))
+    assert p.shape == (B, A) and relmax(p.cpu().numpy(), O.mean_p2cp(u, v)) < 2e-6
+    assert abs(MeanP2CPDistance("mean")(T_(u, dev), T_(v, dev)).item() - O.mean_p2cp(u, v).mean()) < 1e-6
+    assert_close(root.euclidean_distance(out.detach(), tgt).cpu().numpy(), O.euclidean_distance_metric(o.astype(np.float64), g.astype(np.float64)),
+                 rtol=1e-6, atol=1e-7, what="root euclid")
+    xc, yc = root.pearsons_correlation(out.detach(), tgt)
+    # yardstick: the reference's own fp32 evaluation or the fp64 one, whichever is nearer -- over two or three frames the
+    # centred sums cancel and fp32 itself (numpy and stock PyTorch alike) sits 1e-4 from fp64
+    for got, k in ((xc, 0), (yc, 1)):
+        e32 = np.abs(got.cpu().numpy() - O.pearsons_correlation(o, g)[k])
+        e64 = np.abs(got.cpu().numpy() - O.pearsons_correlation(o.astype(np.float64), g.astype(np.float64))[k])
+        assert np.minimum(e32, e64).max() < 2e-5, (B, T, A, N, float(e32.max()), float(e64.max()))
 
 
 def test_tract_variables_match_reference_fixture(dev):
