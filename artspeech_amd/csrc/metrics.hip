@@ -307,36 +307,27 @@ __global__ __launch_bounds__(256) void area_kernel(const double* __restrict__ wi
     }
     __syncthreads();
     if (f >= frames) return;
-    // segment lengths in parallel: lane l holds those of points l, l + 64, l + 128, l + 192 (n <= 256)
-    double seg[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    // The ordered running sum of the reference's loop (d_i = d_{i-1} + seg_i, same order: bit-identical), 64 points at a
+    // time: lane l computes the segment length of point 64 c + l, then every lane runs the same chain on wave-uniform
+    // operands read out of the owners' registers (v_readlane: no LDS round trip per step, the only dependent operation per
+    // step is the add) and keeps the value that belongs to its own point; the row is stored with all lanes (round 2: lane 0
+    // walked LDS and issued 100 single-lane 8-byte stores per frame).
+    double d = 0.0;
+    for (int c = 0; 64 * c < n; ++c) {
         const int i = lane + 64 * c;
-        seg[c] = 0.0;
+        double seg = 0.0;                                   // seg of point 0 is 0.0: d_0 = 0
         if (i >= 1 && i < n) {
             const double dx = __dsub_rn(mx[i], mx[i - 1]), dy = __dsub_rn(my[i], my[i - 1]);
-            seg[c] = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+            seg = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
         }
-    }
-    // The ordered running sum of the reference's loop (d_i = d_{i-1} + seg_i, same order: bit-identical).  Every lane runs
-    // the same chain on wave-uniform operands read out of the owners' registers (v_readlane: no LDS round trip per step,
-    // the only dependent operation per step is the add) and keeps the value that belongs to its own points; the row is
-    // then stored with all lanes (round 2: lane 0 walked LDS and issued 100 single-lane 8-byte stores per frame).
-    double d = 0.0, mine[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (64 * c >= n) break;
         const int lim = min(64, n - 64 * c);
+        double mine = 0.0;
         for (int l = 0; l < lim; ++l) {
-            const int lo = __builtin_amdgcn_readlane(__double2loint(seg[c]), l), hi = __builtin_amdgcn_readlane(__double2hiint(seg[c]), l);
-            d = __dadd_rn(__hiloint2double(hi, lo), d);     // seg of point 0 is 0.0: d_0 = 0
-            mine[c] = l == lane ? d : mine[c];
+            const int lo = __builtin_amdgcn_readlane(__double2loint(seg), l), hi = __builtin_amdgcn_readlane(__double2hiint(seg), l);
+            d = __dadd_rn(__hiloint2double(hi, lo), d);
+            mine = l == lane ? d : mine;
         }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int i = lane + 64 * c;
-        if (i < n) dists[f * n + i] = mine[c];
+        if (i < n) dists[f * n + i] = mine;
     }
 }
 
@@ -640,7 +631,7 @@ extern "C" int as_area_function_fwd(const double* internal_wall, const double* e
                                     int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
                                     double beta, double* dists, double* fx, void* stream) {
     AS_REQUIRE(internal_wall && external_wall && dists && fx && frames > 0, AS_ERR_BAD_ARG, "as_area_function_fwd: bad argument");
-    AS_REQUIRE(n_pts > 0 && n_pts <= 256, AS_ERR_UNSUPPORTED, "as_area_function_fwd: n_pts=%d must be in [1, 256]", n_pts);
+    AS_REQUIRE(n_pts > 0 && n_pts <= 1024, AS_ERR_UNSUPPORTED, "as_area_function_fwd: n_pts=%d must be in [1, 1024]", n_pts);
     const size_t shm = (size_t)4 * 2 * n_pts * sizeof(double);
     hipLaunchKernelGGL(area_kernel, dim3(as_cdiv(frames, 4)), dim3(256), shm, (hipStream_t)stream, internal_wall, external_wall,
                        (long)frame_stride, (long)pt_stride, (long)xy_stride, (long)frames, n_pts, alpha, beta,

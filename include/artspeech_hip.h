@@ -317,7 +317,8 @@ int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int
 
 /* area_function (area_function.py:113-142), float64.  Wall point p, coordinate c of frame f is at
  * w[f*frame_stride + p*pt_stride + c*xy_stride].  dists, fx: [frames][n_pts].  dists is the
- * sequential running sum of mid-line segment lengths (same order as the reference's loop). */
+ * sequential running sum of mid-line segment lengths (same order as the reference's loop).
+ * 1 <= n_pts <= 1024 (the reference's air columns hold 100 points per wall). */
 int as_area_function_fwd(const double* internal_wall, const double* external_wall, int64_t frame_stride,
                          int64_t pt_stride, int64_t xy_stride, int64_t frames, int32_t n_pts, double alpha,
                          double beta, double* dists, double* fx, void* stream);

@@ -965,6 +965,35 @@ def test_area_function_matches_reference_fixture(dev):
         assert np.array_equal(dists[f].cpu().numpy(), od) and np.array_equal(fxs[f].cpu().numpy(), ofx)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_area_function_random_shapes_vs_oracle(dev, seed):
+    """area_function / evenly_spaced_fx (area_function.py:124-159) on seeded random batches: 1-700 frames, 2-1024 wall points,
+    the default and other (alpha, beta), 1-400 resampling abscissae, a wall pair with coincident points (zero-length steps).
+    fp64: bit-identical to the oracle for beta = 2, 1e-14 relative otherwise."""
+    from artspeech_amd.area_function import area_function_batched, evenly_spaced_fx_batched
+    r = np.random.RandomState(900 + seed)
+    frames, nw = int(r.choice([1, 2, 63, 64, 65, 300, 700])), int(r.choice([2, 3, 17, 64, 100, 101, 257, 300, 1024]))
+    ac = r.rand(frames, 2, 2, nw)
+    if seed % 2:
+        ac[:, :, :, nw // 2] = ac[:, :, :, nw // 2 - 1]     # a repeated section: the abscissa does not advance there
+    alpha, beta = [(np.pi, 2.0), (1.5, 1.3), (np.pi, 2.0), (0.7, 3.0)][seed % 4]
+    dists, fxs = area_function_batched(torch.from_numpy(ac).to(dev), alpha=alpha, beta=beta)
+    assert dists.dtype == torch.float64 and tuple(dists.shape) == (frames, nw)
+    d, f = dists.cpu().numpy(), fxs.cpu().numpy()
+    for fr in sorted({0, frames // 2, frames - 1}):
+        od, ofx = O.area_function(ac[fr, 0].T, ac[fr, 1].T, alpha, beta)
+        assert np.array_equal(d[fr], od), fr
+        assert np.array_equal(f[fr], ofx) if beta == 2.0 else relmax(f[fr], ofx) < 1e-14, fr
+    n = int(r.choice([1, 2, 37, 200, 400]))
+    xs = np.cumsum(r.rand(frames, nw) + 1e-3, axis=1)
+    fs = r.rand(frames, nw)
+    out = evenly_spaced_fx_batched(torch.from_numpy(xs).to(dev), torch.from_numpy(fs).to(dev), n).cpu().numpy()
+    assert out.shape == (frames, 2, n)
+    for fr in sorted({0, frames // 2, frames - 1}):
+        ref = O.evenly_spaced_fx(xs[fr], fs[fr], n)
+        assert np.abs(out[fr] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (fr, n)
+
+
 def test_adam_matches_torch(dev):
     from artspeech_amd import _lib
     L = _lib.lib()
