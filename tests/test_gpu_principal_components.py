@@ -58,6 +58,28 @@ def test_matches_oracle(lstm, H, B, T, dev):
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations_vs_oracle(seed, dev):
+    """Seeded random principal-components models (LSTM or GRU cells, hidden 32 / 64 / 128, embedding widths 8-100, 1-4
+    articulators with 1-12 components each, 1-7 utterances of 1-60 frames, ragged) against the numpy oracle
+    (principal_components/models/rnn.py:58-109)."""
+    r = np.random.RandomState(700 + seed)
+    lstm, H, E, V = bool(r.randint(0, 2)), int(r.choice([32, 64, 128])), int(r.choice([8, 20, 64, 100])), int(r.randint(2, 60))
+    names = ["tongue", "lower-lip", "pharynx", "upper-lip"][:int(r.randint(1, 5))]
+    comps = {n: int(r.randint(1, 13)) for n in names}
+    B, T = int(r.randint(1, 8)), int(r.randint(1, 61))
+    torch.manual_seed(seed)
+    m = _model(V, comps, E, H, lstm, None, dev)
+    w = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    lengths = sorted(r.randint(1, T + 1, B).tolist(), reverse=True)
+    lengths[0] = T
+    tokens = torch.from_numpy(r.randint(1, V, (B, T)) if V > 1 else np.zeros((B, T), np.int64))
+    want = PO.forward(w, tokens.numpy(), lengths, lstm)
+    with torch.no_grad():
+        got = m(tokens.to(dev), lengths).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-5, (lstm, H, E, V, comps, B, T, lengths)
+
+
 def test_raw_lstm_kernels_ragged_and_padded(dev):
     """as_lstm_bidir_fwd/bwd on their own: zeros at padded frames (outputs and gate gradients), batch independence."""
     from artspeech_amd import _lib

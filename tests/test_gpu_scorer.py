@@ -78,6 +78,31 @@ def test_scorer_matches_oracle(cfg, B, T, voiced, dev):
     assert np.array_equal(got.argmax(-1)[decided], want.argmax(-1)[decided])
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_scorer_random_configurations_vs_oracle(seed, dev):
+    """Seeded random scorer architectures and inputs (1-4 input planes, 1-3 residual CNN and 1-3 GRU layers, hidden 32 / 64 / 128,
+    3-60 classes, 8-300 features per plane with or without the adapter, 1-3 utterances of 1-150 frames, voicing or not)
+    against the numpy oracle: features and logits within 1e-4, top-1 bit-exact where the oracle's margin exceeds fp32 noise
+    (deepspeech2.py:90-195)."""
+    r = np.random.RandomState(300 + seed)
+    cfg = (int(r.randint(1, 5)), int(r.randint(1, 4)), int(r.randint(1, 4)), int(r.choice([32, 64, 128])), int(r.randint(3, 61)),
+           int(r.choice([8, 24, 50, 80, 100, 130, 200, 300])), int(r.choice([0, 0, 40, 80])))
+    B, T, voiced = int(r.randint(1, 4)), int(r.choice([1, 2, 17, 64, 65, 150])), bool(r.randint(0, 2))
+    w = _random_state(cfg, seed=1000 + seed)
+    m = _model(cfg, w, dev)
+    x = r.rand(B, cfg[0], cfg[5], T).astype(np.float32)
+    v = (r.rand(B, T) > 0.5).astype(np.float32) if voiced else None
+    want, want_f = DO.forward(w, x, v)
+    got, got_f = m(torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev) if voiced else None, return_features=True)
+    got, got_f = got.cpu().numpy().astype(np.float64), got_f.cpu().numpy().astype(np.float64)
+    assert got.shape == want.shape, (cfg, B, T)
+    assert np.abs(got_f - want_f).max() < 1e-4, (cfg, B, T, voiced)
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max()), (cfg, B, T, voiced)
+    srt = np.sort(want, -1)
+    decided = (srt[..., -1] - srt[..., -2]) > 1e-4
+    assert np.array_equal(got.argmax(-1)[decided], want.argmax(-1)[decided]), (cfg, B, T, voiced)
+
+
 def test_scorer_rejects_training_mode_and_cpu_inputs(dev):
     w = _random_state((2, 1, 1, 32, 5, 12, 0), 1)
     m = _model((2, 1, 1, 32, 5, 12, 0), w, dev)
