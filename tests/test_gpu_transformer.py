@@ -123,6 +123,43 @@ def test_medium_config_vs_oracle(dev):
     model.set_encoder_grad_mode(None)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations_forward_vs_oracle(dev, seed):
+    """Seeded random transformer variants (2-6 channels, widths 16-96 with 1-4 heads, 1-3 layers, 4-40 features per channel, 1-4
+    ragged utterances of 1-40 frames, both encoder modes) through the trainer's call (train_..._transformer.py:104-111) against the
+    fp64 oracle: contours within 1e-4 relative."""
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.dataset import pad_sequence_transformer_collate_fn
+    r = np.random.RandomState(4000 + seed)
+    A, L, V = int(r.randint(2, 7)), int(r.randint(1, 4)), int(r.randint(3, 50))
+    d, h = [(16, 1), (16, 4), (32, 2), (48, 4), (64, 4), (64, 1), (96, 2), (96, 3)][int(r.randint(0, 8))]
+    nf = 4 * int(r.randint(1, 11))   # (this build: num_feat and the head width are multiples of 4 -- 16-byte slices; DESIGN section 8)
+    lens = sorted((int(v) for v in r.randint(1, 41, int(r.randint(1, 5)))), reverse=True)
+    torch.manual_seed(seed)
+    model = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf)
+    with torch.no_grad():
+        for k, v in model.named_views().items():
+            if k.endswith("bias") and v.dim() == 1:
+                v.uniform_(-0.2, 0.2)
+    sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    batch = [(f"s{i}", torch.randint(1, V, (l,)), torch.rand(l, A, 2, nf // 2), ["p"] * l, torch.rand(l, 1, 2, nf // 2),
+              torch.tensor([], dtype=torch.int), list(range(l)), torch.zeros(l)) for i, l in enumerate(lens)]
+    c = pad_sequence_transformer_collate_fn(batch)
+    tokens, targets = c[1], c[2]
+    B, T = tokens.shape
+    shifted = torch.cat([torch.zeros(B, 1, A, nf), targets[:, 1:].reshape(B, T - 1, A, nf)], dim=1)
+    for grad_mode in (False, True):
+        model.set_encoder_grad_mode(grad_mode)
+        out = model(tokens.to(dev), shifted.to(dev), src_key_padding_mask=c[8].to(dev), tgt_key_padding_mask=c[9].to(dev),
+                    src_attn_mask=c[10].to(dev), tgt_attn_mask=c[11].to(dev))
+        ref = TO.forward(sd, (V, A, d, h, L, nf), tokens.numpy(), shifted.numpy(), c[10].numpy(), c[11].numpy(), c[8].numpy(),
+                         c[9].numpy(), grad_mode=grad_mode)
+        err = np.abs(out.detach().cpu().numpy() - ref)
+        assert out.shape == ref.shape and (err <= 1e-4 * np.abs(ref) + 1e-6).all(), ((A, d, h, L, nf, lens), grad_mode, err.max())
+    model.set_encoder_grad_mode(None)
+
+
 @pytest.mark.parametrize("A,d,h,lens", [(2, 32, 2, [9, 5]), (3, 48, 4, [12, 12, 7]), (5, 64, 2, [20, 3])])
 def test_edge_configs_vs_oracle_with_directional_derivative(dev, A, d, h, lens):
     """Corners of the block-group node (ops.ChannelBlocks): two channels (ONE interaction block per channel: the
