@@ -105,9 +105,11 @@ class ArtSpeechTransformer(nn.Module):
     def __init__(self, vocab_size: int, num_articulators: int, embed_dim: int = 64, num_heads: int = 4, num_layers: int = 4,
                  num_feat: int = 100, dropout: float = 0.):
         super().__init__()
-        if embed_dim % num_heads or (embed_dim // num_heads) % 4 or num_feat % 4 or num_articulators < 2:
-            raise NotImplementedError("artspeech_amd transformer needs head_dim = embed_dim / num_heads and num_feat to be "
-                                      "multiples of 4 (16-byte aligned slices) and at least 2 articulators")
+        if embed_dim % num_heads or num_feat % 2:
+            raise ValueError("embed_dim must be divisible by num_heads and num_feat must be even (x and y halves)")
+        if embed_dim % 4 or num_articulators < 2:
+            raise NotImplementedError("artspeech_amd transformer needs embed_dim to be a multiple of 4 (16-byte rows for the "
+                                      "grouped GEMM epilogues) and at least 2 articulators")
         A, d, L, nf = num_articulators, embed_dim, num_layers, num_feat
         self.embed_dim, self.num_heads, self.num_layers = d, num_heads, L
         self.num_articulators, self.num_feat, self.vocab_size = A, nf, vocab_size
