@@ -490,6 +490,67 @@ def test_pipelined_engine_is_bit_identical_to_the_unpipelined_one(dev, shape):
     assert torch.isfinite(results[0][3]).all() and results[0][3][-1] < results[0][3][0]
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AS_FUZZ_SEEDS", "10"))))
+def test_engine_random_configurations(dev, seed):
+    """The training engine (one C call per step: fused criterion, fused weight-gradient launches, side streams, optional
+    pipelining across the step boundary) on seeded random architectures and batch shapes -- vocabulary beyond and within the
+    in-kernel token table, hidden sizes of both recurrence families, 1-12 articulators, odd contour sizes, B * T on both
+    sides of the fused launches' thresholds: (1) loss and gradients of the first step equal the module path's (autograd over the
+    drop-in modules, itself swept against the oracle in test_gpu_parity.py); (2) three steps over changing batches leave the
+    pipelined and the unpipelined engine with bit-identical parameters, Adam moments and losses."""
+    from artspeech_amd.engine import TrainStep
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    r = np.random.RandomState(8000 + seed)
+    V, A = int(r.choice([5, 45, 100, 200])), int(r.randint(1, 13))
+    E, H, N = int(r.choice([8, 24, 64])), int(r.choice([32, 64, 128, 128, 44])), int(r.choice([3, 25, 50, 50, 64]))
+    B, T = int(r.randint(1, 13)), int(r.choice([7, 32, 50, 96, 130]))
+    lengths = torch.from_numpy(np.sort(r.randint(1, T + 1, B))[::-1].copy()).int()
+    lengths[0] = T
+    scale = 1.0 / (float(lengths.sum()) * A * N)
+    g = torch.Generator().manual_seed(seed)
+    batches = []
+    for _ in range(3):
+        x = torch.randint(1, V, (B, T), generator=g)
+        tgt = torch.rand(B, T, A, 2, N, generator=g)
+        for b, l in enumerate(lengths):
+            x[b, l:] = 0
+            tgt[b, l:] = 0
+        batches.append((x.to(dev), tgt.to(dev)))
+    ld = lengths.to(dev)
+    what = dict(V=V, A=A, E=E, H=H, N=N, B=B, T=T, lengths=lengths.tolist())
+
+    def make():
+        torch.manual_seed(seed)
+        return ArtSpeech(V, A, embed_dim=E, hidden_size=H, n_samples=N).to(dev)
+
+    model = make()
+    loss = masked_euclidean_loss(model(batches[0][0], lengths), batches[0][1], lengths)
+    loss.backward()
+    ref_grad, ref_loss = model.flat.grad.clone(), loss.item()
+    model = make()
+    step = TrainStep(model, B, T, optimizer=False)
+    step.forward_backward(batches[0][0], ld, batches[0][1], scale)
+    torch.cuda.synchronize()
+    assert abs(step.loss.item() - ref_loss) < 1e-6, what
+    gmax = ref_grad.abs().max().item()
+    assert (step.grads - ref_grad).abs().max().item() <= 2e-6 * gmax, (what, (step.grads - ref_grad).abs().max().item() / gmax)
+    results = []
+    for pipeline in (False, True):
+        model = make()
+        step = TrainStep(model, B, T, lr=1e-3, weight_decay=1e-6, pipeline=pipeline)
+        losses = []
+        for x, tgt in batches:
+            step.step(x, ld, tgt, scale)
+            losses.append(step.loss.clone())
+        step.flush()
+        torch.cuda.synchronize()
+        results.append((model.flat.data.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone(), torch.stack(losses)))
+    for a, b, name in zip(results[0], results[1], ("parameters", "exp_avg", "exp_avg_sq", "losses")):
+        assert torch.equal(a, b), (what, f"pipelined {name} differ: max |diff| {(a - b).abs().max().item():.3e}")
+    assert torch.isfinite(results[0][3]).all()
+
+
 def test_hbm_resident_dataset_collates_like_the_host_collate(dev):
     """HBMResidentDataset.collate (device-side gather / pad, as_gather_pad_rows) returns the tuple of pad_sequence_collate_fn:
     same order, dtypes, padding values (0 / -1), with the tensor fields on the device; run_epoch gives the same loss over it."""
