@@ -551,6 +551,43 @@ def test_engine_random_configurations(dev, seed):
     assert torch.isfinite(results[0][3]).all()
 
 
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_shards_of_the_benchmark_batch_sum_to_the_full_batch(dev, G):
+    """BASELINE configs[2] on one device: the length-sorted batch of 32 ragged utterances dealt round-robin over G ranks
+    (distributed.shard_batch), each rank's engine step with the GLOBAL valid-frame count in its loss scale; the G losses and
+    the G flat gradient buffers must SUM to the full batch's (what the single all-reduce of SURVEY 8e delivers), for the rank
+    batch sizes 16, 8 and 4 of the 2-, 4- and 8-GPU runs."""
+    from artspeech_amd import distributed as dp
+    from artspeech_amd.engine import TrainStep
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    V, A, B, T, N = 45, 11, 32, 200, 50
+    lengths = torch.linspace(200, 60, B).int()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randint(1, V, (B, T), generator=gen)
+    tgt = torch.rand(B, T, A, 2, N, generator=gen)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    torch.manual_seed(2)
+    model = ArtSpeech(V, A).to(dev)
+    full = TrainStep(model, B, T, optimizer=False)
+    full.forward_backward(x.to(dev), lengths.to(dev), tgt.to(dev), dp.loss_scale(int(lengths.sum()), A, N))
+    torch.cuda.synchronize()
+    full_loss, full_grad = full.loss.item(), full.grads.clone()
+    loss_sum, grad_sum = 0.0, torch.zeros_like(full_grad)
+    for r in range(G):
+        xs, ts, ls, n_valid = dp.shard_batch(x, tgt, lengths, r, G)
+        assert n_valid == int(lengths.sum()) and xs.shape[0] == B // G and xs.shape[1] == int(ls[0])
+        shard = TrainStep(model, xs.shape[0], xs.shape[1], optimizer=False)
+        shard.forward_backward(xs.contiguous().to(dev), ls.to(dev), ts.contiguous().to(dev), dp.loss_scale(n_valid, A, N))
+        torch.cuda.synchronize()
+        loss_sum += shard.loss.item()
+        grad_sum += shard.grads
+    assert abs(loss_sum - full_loss) < 1e-6
+    err = (grad_sum - full_grad).abs().max().item() / full_grad.abs().max().item()
+    assert err < 1e-5, err
+
+
 def test_hbm_resident_dataset_collates_like_the_host_collate(dev):
     """HBMResidentDataset.collate (device-side gather / pad, as_gather_pad_rows) returns the tuple of pad_sequence_collate_fn:
     same order, dtypes, padding values (0 / -1), with the tensor fields on the device; run_epoch gives the same loss over it."""
