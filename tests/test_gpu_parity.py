@@ -804,8 +804,13 @@ def test_artspeech_random_configurations_vs_oracle(dev, seed):
     loss.backward()
     o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
     assert_close(out.detach().cpu().numpy(), o_out, what=f"contours {c}")
-    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    o_loss, _ = O.masked_euclid_loss(o_out, tgt, lengths)
     assert abs(loss.item() - o_loss) < 1e-6, c
+    # the criterion's gradient is the unit vector (o - t) / |o - t| per point: where a predicted point all but coincides with
+    # its target, fp32 rounding of the CONTOURS (checked above) is amplified by 1 / distance -- 5e-7 becomes 2e-3 at a
+    # distance of 3e-4, in any fp32 implementation (9 of 1000 draws hold such a point).  The backward is therefore compared
+    # with the oracle's backward AT THE DEVICE'S CONTOURS: same criterion formula, same point of evaluation.
+    _, o_dout = O.masked_euclid_loss(out.detach().cpu().numpy().astype(np.float64), tgt, lengths)
     got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
     og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A)
     assert len(flips) <= 4 and all(abs(z) < 5e-6 for _, _, z in flips), flips
@@ -1137,8 +1142,10 @@ def test_full_size_every_gradient_vs_oracle(dev):
     loss.backward()
     o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
     assert_close(out.detach().cpu().numpy(), o_out, what="contours, full size")
-    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    o_loss, _ = O.masked_euclid_loss(o_out, tgt, lengths)
     assert abs(loss.item() - o_loss) < 1e-6
+    # (criterion gradient evaluated at the device's contours: see test_artspeech_random_configurations_vs_oracle)
+    _, o_dout = O.masked_euclid_loss(out.detach().cpu().numpy().astype(np.float64), tgt, lengths)
     got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
     og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A)
     assert len(flips) <= 8 and all(abs(z) < 5e-6 for _, _, z in flips), flips
