@@ -72,6 +72,7 @@ def _slab(dev):
 def _gemm(A, W, bias, out, act=0, split_k=False):
     """out[M][N] = act(A[M][K] . W[N][K]^T + bias).  split_k (act == 0 only): few output tiles under a long reduction --
     the bias is laid down first and the GEMM accumulates onto it, its K range split over workgroups (deterministic slabs)."""
+    assert A.is_contiguous() and W.is_contiguous() and out.is_contiguous(), "bare pointers below: dense row-major operands"
     g = _lib.Gemm()
     g.A, g.B, g.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
     g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
@@ -89,6 +90,7 @@ def _gemm(A, W, bias, out, act=0, split_k=False):
 
 def _ln(x, ln, out):
     rows, D = x.shape
+    assert x.is_contiguous() and out.is_contiguous(), "bare pointers below: dense row-major operands"
     _lib.check(_lib.lib().as_layernorm_fwd(_lib.ptr(x), None, _lib.ptr(ln.weight), _lib.ptr(ln.bias), _lib.ptr(out), None, None,
                                            rows, D, 0, _lib.stream_ptr()), "as_layernorm_fwd")
     return out
@@ -163,7 +165,9 @@ class DeepSpeech2(nn.Module):
         with torch.no_grad():
             if self.adapter is not None:
                 ad = self.adapter.adapter
-                rows = x.transpose(2, 3).reshape(B * Cin * T, Din)  # the reference's own transpose (:84); glue copy of the input
+                # the reference's own transpose (:84); glue copy of the input.  (.contiguous(): with B = C = 1 the reshape of the
+                # transposed view is itself a VIEW with strides (1, T) -- the kernels below take bare pointers)
+                rows = x.transpose(2, 3).reshape(B * Cin * T, Din).contiguous()
                 a = _ln(rows, ad[0], torch.empty_like(rows))
                 a = _gemm(a, ad[1].weight, ad[1].bias, torch.empty(rows.shape[0], D, device=dev, dtype=f32))
                 a = _ln(a, ad[2], torch.empty_like(a))

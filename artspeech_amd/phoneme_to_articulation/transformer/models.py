@@ -373,7 +373,7 @@ class ArtSpeechTransformer(nn.Module):
         w, b = self._fold(P["tgt_w"][None], P["tgt_ln_w"][None], P["tgt_ln_b"][None], P["tgt_b"][None])
         emb = GroupedLinear.apply(that[None], w, b, (0,), True).view(B, T, A, d)
         x = F.dropout(emb + self.pe[0, :T].view(1, T, 1, d), self.dropout, train)            # positional encoding per channel
-        x = x.permute(2, 0, 1, 3).reshape(A, R, d)                                             # channel-major
+        x = x.permute(2, 0, 1, 3).reshape(A, R, d).contiguous()   # channel-major (with T = 1 the reshape alone is a strided view)
         mem_hat = Normalize.apply(memory)[None] if memory_kv is None else None                 # shared by every cross block
         # ARTSPEECH_CHECKPOINT_LAYERS=1 (or model.checkpoint_layers = True): keep only each decoder layer's INPUT for the
         # backward and recompute the layer's forward there (every op is an autograd Function, so torch.utils.checkpoint
@@ -391,7 +391,7 @@ class ArtSpeechTransformer(nn.Module):
                                     last_only=last_only and l == self.num_layers - 1)
         if last_only:  # x is [A, B, d]: the newest frame only
             T, R = 1, B
-        feat = F.dropout(x.permute(1, 0, 2).reshape(R, A * d), self.dropout, train)
+        feat = F.dropout(x.permute(1, 0, 2).reshape(R, A * d).contiguous(), self.dropout, train)
         w, b = self._fold(P["fin_w"][None], P["fin_ln_w"][None], P["fin_ln_b"][None], P["fin_b"][None])
         feat = GroupedLinear.apply(Normalize.apply(feat)[None], w, b, (0,), True)[0]
         out = Heads.apply(feat, P["head_flat"], self.head_dims, self.head_lay)
