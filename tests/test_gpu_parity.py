@@ -818,6 +818,60 @@ def test_artspeech_random_configurations_vs_oracle(dev, seed):
         assert_grad_close(v, og[k], f"{c} (ReLU decisions taken from the device: {flips}): {k}")
 
 
+def test_entry_points_accept_strided_and_degenerate_views(dev):
+    """The kernels take bare pointers, the Python entry points take whatever tensor the caller has: row-sliced, transposed,
+    step-sliced and size-1-dimension views (where `reshape` returns a strided view instead of a copy -- the scorer's round-3
+    bug) must give exactly what their dense copies give."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech, SimpleArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance, masked_euclidean_loss
+    from artspeech_amd.tract_variables import tract_variables_batched
+    from artspeech_amd.area_function import area_function_batched, evenly_spaced_fx_batched
+    from artspeech_amd import metrics as root
+    torch.manual_seed(0)
+    V, A, B, T, N = 30, 3, 4, 9, 50
+    lengths = torch.tensor([9, 7, 4, 1], dtype=torch.int32)
+    big = torch.randint(1, V, (B, 2 * T + 3), device=dev)
+    views = {"row-sliced": big[:, :T], "step-sliced": big[:, 0:2 * T:2], "transposed": big[:, :T].t().contiguous().t()}
+    for model in (ArtSpeech(V, A).to(dev), SimpleArtSpeech(V, A).to(dev)):
+        for name, x in views.items():
+            assert not x.is_contiguous(), name
+            with torch.no_grad():
+                assert torch.equal(model(x, lengths), model(x.contiguous(), lengths)), (type(model).__name__, name)
+        for Bx, Tx in ((1, 5), (3, 1), (1, 1)):   # size-1 dimensions
+            x = big[:Bx, 3:3 + 2 * Tx:2]
+            with torch.no_grad():
+                assert torch.equal(model(x, lengths[:Bx].clamp(max=Tx)), model(x.contiguous(), lengths[:Bx].clamp(max=Tx))), (Bx, Tx)
+    o = torch.rand(B, T, 2, N, A, device=dev).permute(0, 1, 4, 2, 3)      # (B, T, A, 2, N) view of another layout
+    g = torch.rand(B, 2 * T, A, 2, N, device=dev)[:, ::2]
+    assert not o.is_contiguous() and not g.is_contiguous()
+    oc, gc = o.contiguous(), g.contiguous()
+    assert torch.equal(EuclideanDistance("none")(o, g), EuclideanDistance("none")(oc, gc))
+    assert torch.equal(masked_euclidean_loss(o, g, lengths), masked_euclidean_loss(oc, gc, lengths))
+    assert torch.equal(MeanP2CPDistance("none")(o.transpose(-1, -2), g.transpose(-1, -2)), MeanP2CPDistance("none")(oc.transpose(-1, -2), gc.transpose(-1, -2)))
+    assert torch.equal(root.p2cp_distance(o, g), root.p2cp_distance(oc, gc))
+    assert torch.equal(root.euclidean_distance(o, g), root.euclidean_distance(oc, gc))
+    for a_, b_ in zip(root.pearsons_correlation(o, g), root.pearsons_correlation(oc, gc)):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(root.pearsons_correlation(o[1:2, :1], g[1:2, :1]), root.pearsons_correlation(oc[1:2, :1], gc[1:2, :1])):   # (1, 1, ...) views
+        assert torch.equal(a_, b_)
+    arts = sorted(["arytenoid-cartilage", "epiglottis", "lower-incisor", "lower-lip", "pharynx", "soft-palate-midline",
+                   "thyroid-cartilage", "tongue", "upper-incisor", "upper-lip", "vocal-folds"])
+    fr = torch.rand(7, 2, 11, N, device=dev).transpose(1, 2)               # (frames, A, 2, N) view
+    for a_, b_ in zip(tract_variables_batched(fr, arts), tract_variables_batched(fr.contiguous(), arts)):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(tract_variables_batched(fr[:1], arts), tract_variables_batched(fr[:1].contiguous(), arts)):
+        assert torch.equal(a_, b_)
+    ac = torch.rand(5, 2, 100, 2, device=dev, dtype=torch.float64).transpose(2, 3)   # (frames, walls, 2, Nw) view
+    for a_, b_ in zip(area_function_batched(ac), area_function_batched(ac.contiguous())):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(area_function_batched(ac[:1]), area_function_batched(ac[:1].contiguous())):
+        assert torch.equal(a_, b_)
+    xs = torch.cumsum(torch.rand(100, 6, device=dev, dtype=torch.float64) + 1e-3, dim=0).t()   # (frames, Nw) view
+    fs = torch.rand(6, 200, device=dev, dtype=torch.float64)[:, ::2]
+    assert torch.equal(evenly_spaced_fx_batched(xs, fs, 37), evenly_spaced_fx_batched(xs.contiguous(), fs.contiguous(), 37))
+    assert torch.equal(evenly_spaced_fx_batched(xs[:1], fs[:1], 37), evenly_spaced_fx_batched(xs[:1].contiguous(), fs[:1].contiguous(), 37))
+
+
 # ------------------------------------------------------------------------------------------- metrics
 def test_metrics_match_reference_fixture(dev):
     from artspeech_amd.phoneme_to_articulation.metrics import EuclideanDistance, MeanP2CPDistance

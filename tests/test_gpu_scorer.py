@@ -106,6 +106,17 @@ def test_scorer_random_configurations_vs_oracle(seed, dev):
     assert np.array_equal(got.argmax(-1)[decided], want.argmax(-1)[decided]), (cfg, B, T, voiced)
 
 
+def test_scorer_accepts_strided_and_degenerate_views(dev):
+    """The pipeline hands the scorer a permuted view of the contours (synthetic_shapes.py:133-135); sliced voicing; one plane,
+    one utterance, one frame: all exactly what their dense copies give."""
+    for cfg, B, T in (((2, 1, 1, 32, 9, 24, 16), 2, 9), ((1, 1, 1, 32, 9, 24, 16), 1, 9), ((1, 1, 1, 32, 9, 24, 0), 1, 1), ((3, 1, 1, 32, 9, 24, 16), 1, 1)):
+        w = _random_state(cfg, seed=3)
+        m = _model(cfg, w, dev)
+        x = torch.rand(T, cfg[0], cfg[5], B, device=dev).permute(3, 1, 2, 0)      # (B, planes, D, T) view
+        v = (torch.rand(B, 2 * T, device=dev) > 0.5).float()[:, ::2]
+        assert torch.equal(m(x, v), m(x.contiguous(), v.contiguous())), (cfg, B, T)
+
+
 def test_scorer_rejects_training_mode_and_cpu_inputs(dev):
     w = _random_state((2, 1, 1, 32, 5, 12, 0), 1)
     m = _model((2, 1, 1, 32, 5, 12, 0), w, dev)

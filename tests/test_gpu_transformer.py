@@ -173,6 +173,27 @@ def test_random_configurations_forward_vs_oracle(dev, seed):
         assert (err <= 1e-4 * np.abs(ref[:, -1]) + 1e-6).all(), ((A, d, h, L, nf, lens), err.max())
 
 
+def test_forward_accepts_strided_and_degenerate_views(dev):
+    """Row-sliced / step-sliced / permuted tokens, targets and masks, and batches with B = 1 or T = 1 (where reshapes of
+    permuted tensors are strided views), give exactly what their dense copies give."""
+    from artspeech_amd.phoneme_to_articulation.transformer.models import ArtSpeechTransformer
+    torch.manual_seed(1)
+    V, A, d, h, L, nf = 11, 3, 32, 2, 2, 12
+    model = ArtSpeechTransformer(V, A, embed_dim=d, num_heads=h, num_layers=L, num_feat=nf).to(dev).eval()
+    for B, T in ((3, 7), (1, 6), (4, 1), (1, 1)):
+        src = torch.randint(1, V, (B, 2 * T + 1), device=dev)[:, 1:2 * T:2]
+        tgt = torch.rand(B, A, T, nf, device=dev).permute(0, 2, 1, 3)
+        kpm = torch.zeros(T, B, device=dev).t()
+        causal = torch.full((T, T), float("-inf"), device=dev).triu(1)
+        mask = causal.expand(B, T, T)
+        with torch.no_grad():
+            got = model(src, tgt, src_key_padding_mask=kpm, tgt_key_padding_mask=kpm, src_attn_mask=mask, tgt_attn_mask=mask)
+            want = model(src.contiguous(), tgt.contiguous(), src_key_padding_mask=kpm.contiguous(), tgt_key_padding_mask=kpm.contiguous(),
+                         src_attn_mask=mask.contiguous(), tgt_attn_mask=mask.contiguous())
+            assert torch.equal(got, want), (B, T)
+            assert torch.equal(model.generate(src, kpm), model.generate(src.contiguous(), kpm.contiguous())), (B, T)
+
+
 @pytest.mark.parametrize("A,d,h,lens,nf", [(2, 32, 2, [9, 5], 20), (3, 48, 4, [12, 12, 7], 20), (5, 64, 2, [20, 3], 20), (3, 32, 2, [11, 4], 6), (2, 64, 4, [7, 7], 10), (3, 28, 4, [9, 6], 6), (2, 12, 4, [8], 2), (3, 20, 2, [5, 5, 2], 10)])
 def test_edge_configs_vs_oracle_with_directional_derivative(dev, A, d, h, lens, nf):
     """Corners of the block-group node (ops.ChannelBlocks): two channels (ONE interaction block per channel: the
