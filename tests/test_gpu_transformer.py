@@ -194,7 +194,21 @@ def test_forward_accepts_strided_and_degenerate_views(dev):
             assert torch.equal(model.generate(src, kpm), model.generate(src.contiguous(), kpm.contiguous())), (B, T)
 
 
-@pytest.mark.parametrize("A,d,h,lens,nf", [(2, 32, 2, [9, 5], 20), (3, 48, 4, [12, 12, 7], 20), (5, 64, 2, [20, 3], 20), (3, 32, 2, [11, 4], 6), (2, 64, 4, [7, 7], 10), (3, 28, 4, [9, 6], 6), (2, 12, 4, [8], 2), (3, 20, 2, [5, 5, 2], 10)])
+def _drawn_training_configs(n):
+    """seeded random (A, d, h, lens, nf) for the backward check below: 2-5 channels, widths 12-64 incl. odd head widths, 1-3
+    ragged utterances of 1-14 frames, 2-24 features per channel"""
+    out = []
+    for s in range(n):
+        r = np.random.RandomState(6000 + s)
+        d, h = [(12, 4), (16, 1), (20, 5), (28, 4), (32, 2), (48, 4), (64, 4)][int(r.randint(0, 7))]
+        lens = sorted((int(v) for v in r.randint(1, 15, int(r.randint(1, 4)))), reverse=True)
+        out.append((int(r.randint(2, 6)), d, h, lens, 2 * int(r.randint(1, 13))))
+    return out
+
+
+@pytest.mark.parametrize("A,d,h,lens,nf", [(2, 32, 2, [9, 5], 20), (3, 48, 4, [12, 12, 7], 20), (5, 64, 2, [20, 3], 20), (3, 32, 2, [11, 4], 6),
+                                           (2, 64, 4, [7, 7], 10), (3, 28, 4, [9, 6], 6), (2, 12, 4, [8], 2), (3, 20, 2, [5, 5, 2], 10)]
+                         + _drawn_training_configs(int(os.environ.get("AS_FUZZ_SEEDS", "8"))))
 def test_edge_configs_vs_oracle_with_directional_derivative(dev, A, d, h, lens, nf):
     """Corners of the block-group node (ops.ChannelBlocks): two channels (ONE interaction block per channel: the
     concatenation is a single block wide), a head width the fused attention kernel does not take (48 / 4 = 12: the unfused
@@ -236,15 +250,18 @@ def test_edge_configs_vs_oracle_with_directional_derivative(dev, A, d, h, lens, 
     direction = {k: rng.randn(*v.shape) * (np.abs(v).mean() + 1e-3) for k, v in sd.items() if not k.endswith(".pe")}
     analytic = sum(float((g.cpu().numpy().astype(np.float64) * direction[k]).sum()) for k, g in model.named_grad_views().items())
     w64 = wgt.cpu().numpy().astype(np.float64)
-    eps = 1e-7   # (fp64 oracle: small enough that the joint step crosses next to no ReLU kink; 1e-5 is 1 % off)
+    # central differences of the fp64 oracle at two step sizes: a ReLU kink inside [-eps, +eps] along the joint direction bends
+    # the difference quotient at that step size (one draw of the round-3 sweep: -20.40220 at 1e-8, -20.83 at 1e-7, analytic
+    # -20.40221), so the nearer of the two is the yardstick; 1e-5 is 1 % off in most draws
+    def numeric_at(eps):
+        def loss_at(sign):
+            moved = {k: (v + sign * eps * direction[k] if k in direction else v) for k, v in sd.items()}
+            return float((TO.forward(moved, cfg, *args, grad_mode=True) * w64).sum())
+        return (loss_at(+1) - loss_at(-1)) / (2 * eps)
 
-    def loss_at(sign):
-        moved = {k: (v + sign * eps * direction[k] if k in direction else v) for k, v in sd.items()}
-        return float((TO.forward(moved, cfg, *args, grad_mode=True) * w64).sum())
-
-    numeric = (loss_at(+1) - loss_at(-1)) / (2 * eps)
-    # (a wrong term in the hand-written backward shows up at the per-cent level; fp32 rounding of the analytic side and the few
-    # kinks the step still crosses stay below 5e-4: measured 4e-6 .. 4.5e-4 over the three configurations)
+    numeric = min((numeric_at(e) for e in (1e-7, 1e-8)), key=lambda v: abs(v - analytic))
+    # (a wrong term in the hand-written backward shows up at the per-cent level at EVERY step size; fp32 rounding of the analytic
+    # side stays below 5e-4: measured 4e-6 .. 4.5e-4 over the first three configurations)
     assert abs(analytic - numeric) <= 1e-3 * max(abs(numeric), 1.0), (analytic, numeric)
     model.set_encoder_grad_mode(None)
 
