@@ -789,7 +789,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     AS_REQUIRE((g->b_j == 1) != (g->b_k == 1) || (g->b_j == 1 && g->b_k == 1 && (g->N == 1 || g->K == 1)),
                AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of b_j/b_k must be 1 (b_j=%ld b_k=%ld)", (long)g->b_j, (long)g->b_k);
     AS_REQUIRE(g->act >= 0 && g->act <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
-    const bool a_kc = g->a_k == 1, b_kc = g->b_k == 1;
+    // (M == 1 with both strides of A equal to 1 reads the same either way: output-contiguous then, the form the column sums take)
+    const bool a_kc = g->a_k == 1 && !(g->a_i == 1 && g->colsum), b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
     if (!a_kc && !b_kc && g->k_tri == 0) {  // weight-gradient shapes: the kernel of wgrad_f32.hip (it does not know k_tri)
         const int taken = as_wgrad_try(g, (hipStream_t)stream);
