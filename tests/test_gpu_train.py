@@ -602,7 +602,9 @@ def test_hbm_resident_dataset_collates_like_the_host_collate(dev):
     ds = SyntheticArtSpeechDataset(21, voc, ARTS, n_samples=50, min_len=1, max_len=33, seed=4, voiced_tokens=["p1", "p4"])
     rds = HBMResidentDataset(ds, dev)
     assert len(rds) == len(ds) and rds.dataset_config is ds.dataset_config
-    for idx in ([3, 0, 7, 12, 20], [5], list(range(21))):
+    r = np.random.RandomState(0)   # + 25 seeded index lists: any size, any order, repeats allowed (a sampler with replacement)
+    drawn = [r.randint(0, 21, int(r.randint(1, 22))).tolist() for _ in range(25)]
+    for idx in [[3, 0, 7, 12, 20], [5], list(range(21))] + drawn:
         want = pad_sequence_collate_fn([ds[i] for i in idx])
         got = rds.collate(idx)
         assert got[0] == want[0] and got[4] == want[4] and got[6] == want[6]
