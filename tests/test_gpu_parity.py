@@ -1165,10 +1165,13 @@ def test_full_size_matches_reference_fixture(dev):
         sl = gv[k].reshape(-1)[:: max(1, gv[k].size // 257)][:257]
         # tolerance scaled by the whole tensor's max (from the fixture).  Wider than the small fixtures' 1e-5: of the 18 M
         # ReLU decisions per head layer at this size a handful sit within an ulp of zero and differ between any two fp32
-        # evaluation orders, each moving a gradient element by one full frame term (tests/test_oracle_golden.py measures
-        # up to 2.5e-3 of max|g| between the reference and the fp64 oracle; this path: 1.5e-3 on embedding.weight, where the
-        # oracle shows 1.3e-3 too, <= 1e-4 elsewhere)
-        assert_grad_close(sl, g["gslice." + k], f"c2 full: {k}", atol_abs=5e-3 * float(g["gmax." + k]))
+        # evaluation orders, each moving the gradient elements downstream of it by one full frame term
+        # (tests/test_oracle_golden.py measures up to 2.5e-3 of max|g| between the REFERENCE and the fp64 oracle).  This
+        # path, measured over all 173 tensors (profiles/r03_parity_worst_errors.json, rescaled to the tensor's max): worst
+        # 1.3e-3 (predictors.6.linear.1.bias), 1.15e-3 on embedding.weight, 90th percentile 2.9e-4, median 2.9e-7 -- so the floor is the reference's
+        # own 2.5e-3, not more.  The check WITHOUT this allowance is test_full_size_every_gradient_vs_oracle below: every
+        # element of every gradient at 1e-4 |ref| + 1e-5 max|ref| with the device's ReLU decisions handed to the oracle.
+        assert_grad_close(sl, g["gslice." + k], f"c2 full: {k}", atol_abs=2.5e-3 * float(g["gmax." + k]))
 
 
 def test_full_size_every_gradient_vs_oracle(dev):
