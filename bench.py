@@ -111,19 +111,27 @@ def pmc_traffic(kernel):
     return None
 
 
-def measured_copy_gbs(dev, mib=1024, reps=10):
-    """Streaming copy rate of THIS box (read + write bytes over time, a 1 GiB fp32 tensor copied `reps` times): the
-    measured denominator SURVEY 8(d) asks for beside the 8 TB/s spec figure."""
+def measured_copy_gbs(dev, mib=1024, reps=64):
+    """Streaming copy rate of THIS box (read + write bytes over time, a 1 GiB fp32 tensor copied `reps` times; the rate of
+    the LAST quarter of the copies counts): the measured denominator SURVEY 8(d) asks for beside the 8 TB/s spec figure.
+
+    A GPU that has been idle raises its clocks over its first ~20 ms of work (tools/step_warmup_curve.py: the step time of
+    this benchmark falls smoothly from 1.23 to 1.10 ms over the first 20 steps of a process,
+    profiles/r03_step_warmup_curve.txt), hence 64 copies with the last 16 counted.
+    Returns (GB/s, milliseconds the probe kept the GPU busy)."""
     src = torch.empty(mib << 18, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
     dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tail = max(1, reps // 4)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
-    for _ in range(reps):
+    for i in range(reps):
+        if i == reps - tail:
+            e1.record()
         dst.copy_(src)
-    e1.record()
+    e2.record()
     torch.cuda.synchronize()
-    return round(2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    return round(2.0 * src.numel() * 4 * tail / (e1.elapsed_time(e2) * 1e-3) / 1e9, 1), round(e0.elapsed_time(e2), 2)
 
 
 def host_cores():
@@ -367,7 +375,7 @@ def main():
                 roofline, other, other_key = l1, l0, "layer0_variant"
             roofline["note"] = "dependent-step (latency) bound: 200 sequential recurrent steps per launch"
             roofline["traffic_source"] = "committed rocprofv3 --pmc passes of the same command (profiles/rNN_pmc_traffic.json), not this run"
-            copy_gbs = measured_copy_gbs(dev)
+            copy_gbs, _ = measured_copy_gbs(dev)
             roofline["peak_measured_copy"] = copy_gbs   # the box's own streaming-copy rate beside the 8 TB/s spec
             roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5)
             if other is not None:
