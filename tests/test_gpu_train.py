@@ -650,3 +650,16 @@ def test_criterion_fused_into_the_output_layer_equals_the_separate_kernel(dev):
     assert torch.equal(res[0][1], res[1][1]), "d loss / d(pre-sigmoid) differs"
     assert torch.equal(res[0][2], res[1][2]), "gradients differ"
     assert abs(res[0][3] - res[1][3]) < 1e-7 and np.isfinite(res[0][3])
+
+
+def test_rccl_single_rank_engine_is_bit_identical(dev):
+    """The engine's data-parallel step over a ONE-rank RCCL group (child process, tests/_rccl_single_rank_worker.py): the
+    overlapped two-piece all-reduce on the communication stream and the late slice's all-reduce run through the real backend
+    (a one-GPU box cannot hold two RCCL ranks; the world-2 arithmetic is covered by the gloo test in tests/test_host.py)."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_single_rank_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl single rank ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
