@@ -106,6 +106,8 @@ PROTOTYPES = {
     "as_add": (_I32, [_P, _P, _P, _I64, _P]),
     "as_row_scale": (_I32, [_P, _P, _P, _I64, _I32, _P]),
     "as_set_overlap": (None, [_I32]),
+    "as_set_matrix_arith": (None, [_I32]),
+    "as_get_matrix_arith": (_I32, []),
     "as_conv3x3_stem": (_I32, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "as_conv3x3_c32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "as_ln_feat_gelu": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),

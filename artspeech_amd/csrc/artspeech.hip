@@ -39,7 +39,11 @@ struct Carve {
 struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t xhat, rstd0, w1f, b1f, w2f, b2f, w3f, b3f, r1, r1hat, rstd1, r2, r2hat, rstd2;
     int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, slab3, bits1, bits2, lpart, lpart_n, total;
+    // the folded weights as bfloat16 planes (as_emit_planes): forward orientation [rows = out features][k = in features] and,
+    // for the input-gradient chain, transposed [rows = in features][k = out features]
+    int64_t w1p, w2p, w3p, w2tp, w3tp;
 };
+constexpr int OUT_BN = 128;   // column tile of the output layer's kernel (lin_out): rows of the W3' planes per head
 
 HeadWs head_ws(const as_dims& d, int64_t rows) {
     const int64_t A = d.n_art, H = d.hidden, O = 2 * d.n_samp;
@@ -75,6 +79,12 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.bits2 = c.take(rows * A * (D / 64) * 2);
     w.lpart_n = (rows / 32 + 2) * A;      // workgroup partial sums of the fused criterion (one per output-layer tile)
     w.lpart = c.take(w.lpart_n);
+    const int Opad = (int)as_round_up(O, 32);
+    w.w1p = c.take(as_planes_floats((int)A, D, (int)as_round_up(H, 32)));
+    w.w2p = c.take(as_planes_floats((int)A, D, D));
+    w.w3p = c.take(as_planes_floats((int)A, (int)as_round_up(O, OUT_BN), D));
+    w.w2tp = c.take(as_planes_floats((int)A, D, D));
+    w.w3tp = c.take(as_planes_floats((int)A, D, Opad));
     w.total = c.off;
     return w;
 }
@@ -167,6 +177,20 @@ int head_fold(const as_dims& d, const as_layout& L, const float* P, int64_t rows
     AS_STEP("head.fold", st, as_fold(P + L.w1, P + L.ln1_g, P + L.ln1_b, P + L.b1, ws + w.w1f, ws + w.b1f, A, D, H, st));
     AS_STEP("head.fold", st, as_fold(P + L.w2, P + L.ln2_g, P + L.ln2_b, P + L.b2, ws + w.w2f, ws + w.b2f, A, D, D, st));
     AS_STEP("head.fold", st, as_fold(P + L.w3, P + L.ln3_g, P + L.ln3_b, P + L.b3, ws + w.w3f, ws + w.b3f, A, O, D, st, (int)as_round_up(O, 32)));
+    if (as_matrix_arith() == AS_ARITH_BF16X6 && H % 4 == 0) {
+        // the folded weights as bfloat16 planes for the split-arithmetic kernels: forward orientation, and transposed for
+        // the input-gradient chain (d(x_hat) = dz . W': the reduction runs over W' rows)
+        const int Opad = (int)as_round_up(O, 32), Hp = (int)as_round_up(H, 32);
+        auto up = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
+        as_planes_job j[5] = {
+            {ws + w.w1f, H, 1, (long)D * H, A, D, H, D, Hp, up(w.w1p)},
+            {ws + w.w2f, D, 1, (long)D * D, A, D, D, D, D, up(w.w2p)},
+            {ws + w.w3f, D, 1, (long)Opad * D, A, O, D, (int)as_round_up(O, OUT_BN), D, up(w.w3p)},
+            {ws + w.w2f, 1, D, (long)D * D, A, D, D, D, D, up(w.w2tp)},
+            {ws + w.w3f, 1, D, (long)Opad * D, A, D, O, D, Opad, up(w.w3tp)},
+        };
+        AS_STEP("head.planes", st, as_emit_planes(j, 5, st));
+    }
     return 0;
 }
 
@@ -193,6 +217,11 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     l1.bias = ws + w.b1f; l1.bias_batch = D;
     l1.M = R; l1.N = D; l1.K = H; l1.batch = A; l1.epi = 1;
     l1.rstd = ws + w.rstd1; l1.bits = bits1;
+    const uint16_t* w1p = reinterpret_cast<const uint16_t*>(ws + w.w1p);
+    const uint16_t* w2p = reinterpret_cast<const uint16_t*>(ws + w.w2p);
+    if (H % 32 == 0) {
+        l1.Bp = w1p; l1.bp_rows = D; l1.bp_batch = as_planes_batch_stride(D, H); l1.bp_plane = A * l1.bp_batch;
+    }
     int took;
     {
         AS_PROF("head.gemm1", st);
@@ -209,6 +238,7 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     l2.B = ws + w.w2f; l2.ldb = D; l2.b_batch = (long)D * D;
     l2.C = ws + w.r2hat; l2.bias = ws + w.b2f;
     l2.K = D; l2.rstd = ws + w.rstd2; l2.bits = bits2;
+    l2.Bp = w2p; l2.bp_rows = D; l2.bp_batch = as_planes_batch_stride(D, D); l2.bp_plane = A * l2.bp_batch;
     {
         AS_PROF("head.gemm2", st);
         took = as_lin_try(&l2, st);
@@ -281,6 +311,8 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     b3.C = ws + w.dz2; b3.ldc = AD; b3.c_batch = D;
     b3.M = R; b3.N = D; b3.K = Opad; b3.ka_valid = O; b3.batch = A; b3.epi = 2;
     b3.xhat = ws + w.r2hat; b3.ldx = AD; b3.x_batch = D; b3.rstd_in = ws + w.rstd2; b3.bits_in = bits2;
+    b3.Bp = reinterpret_cast<const uint16_t*>(ws + w.w3tp); b3.bp_rows = D; b3.bp_batch = as_planes_batch_stride(D, Opad);
+    b3.bp_plane = A * b3.bp_batch;
     int took;
     {
         AS_PROF("headb.dx3", st);
@@ -296,6 +328,7 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
     b2.B = ws + w.w2f; b2.b_batch = (long)D * D;
     b2.C = ws + w.dz1; b2.K = D; b2.ka_valid = D;
     b2.xhat = ws + w.r1hat; b2.rstd_in = ws + w.rstd1; b2.bits_in = bits1;
+    b2.Bp = reinterpret_cast<const uint16_t*>(ws + w.w2tp); b2.bp_batch = as_planes_batch_stride(D, D); b2.bp_plane = A * b2.bp_batch;
     {
         AS_PROF("headb.dx2", st);
         took = as_lin_try(&b2, st);

@@ -16,6 +16,24 @@ struct as_wgrad_job {
 };
 int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st);
 
+// How fp32 matrix products are formed (as_set_matrix_arith, include/artspeech_hip.h):
+//   AS_ARITH_FP32    v_mfma_f32_32x32x2_f32 on the fp32 operands (every kernel has this path)
+//   AS_ARITH_BF16X6  operands split exactly into three bfloat16 planes, six plane products on v_mfma_f32_32x32x16_bf16,
+//                    fp32 accumulation -- where a kernel has the path (the default)
+enum { AS_ARITH_FP32 = 0, AS_ARITH_BF16X6 = 1 };
+int as_matrix_arith();
+
+// rowops.hip: B[batch][n][k] (element strides n_stride, k_stride, batch_stride) as three bfloat16 planes
+// out[plane][batch][Kpad / 16][rows_pad][16] (x = hi + mid + lo exactly; n >= N or k >= K: zeros).  Up to 8 jobs, one launch.
+struct as_planes_job {
+    const float* B; long n_stride, k_stride, batch_stride;
+    int batch, N, K, rows_pad, Kpad;
+    uint16_t* out;      // plane stride = batch * (Kpad / 16) * rows_pad * 16 elements, batch stride = (Kpad / 16) * rows_pad * 16
+};
+int as_emit_planes(const as_planes_job* jobs, int n, hipStream_t st);
+static inline long as_planes_batch_stride(int rows_pad, int Kpad) { return (long)(Kpad / 16) * rows_pad * 16; }
+static inline long as_planes_floats(int batch, int rows_pad, int Kpad) { return 3 * batch * as_planes_batch_stride(rows_pad, Kpad) / 2; }
+
 // lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):
 //   C[bz] = epilogue(A[bz] [M][K] . B[bz]),  B[bz] = [N][K] (b_kc: forward) or [K][N] (backward); N <= 256, K % 32 == 0.
 //   epi 0: act(. + bias) (act as as_gemm: 0 none, 1 ReLU, 2 sigmoid)
@@ -26,6 +44,10 @@ int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_float
 struct as_lin {
     const float* A; long lda, a_batch;
     const float* B; long ldb, b_batch; int b_kc;
+    // optional: the same B as three bfloat16 planes [plane][batch][K / 16][bp_rows][16] (as_emit_planes; rows >= N zero,
+    // strides in bf16 elements).  With as_matrix_arith() == AS_ARITH_BF16X6 and K % 32 == 0 the layer then runs on the bf16
+    // matrix instruction (six plane products per fp32 product, fp32 accumulate: lin_s6_kernel); B itself is not read.
+    const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;
     float* C; long ldc, c_batch;
     const float* bias; long bias_batch;
     int M, N, K, ka_valid, batch, act, epi;

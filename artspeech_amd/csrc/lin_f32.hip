@@ -37,6 +37,7 @@ enum { EPI_PLAIN = 0, EPI_LNF = 1, EPI_LNB = 2 };
 struct LinK {
     const float* A; long lda, a_batch;
     const float* B; long ldb, b_batch;
+    const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // lin_s6_kernel: B as three bfloat16 planes (as_lin.Bp)
     float* C; long ldc, c_batch;
     const float* bias; long bias_batch;
     int M, N, K, ka_valid, batch, act;
@@ -96,6 +97,114 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ void lds_barrier() {  // LDS hazards only: unlike __syncthreads() it leaves global stores in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+}
+
+// ---- epilogue of the 256-column kernels (8 waves, wave w owns columns 32 w .. 32 w + 31 of all BM rows).
+// D[row][col]: col = wave * 32 + l31, row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh -- the accumulator layout of
+// v_mfma_f32_32x32x2_f32 and of v_mfma_f32_32x32x16_bf16 alike.  `smem`: >= 32 * BN floats, free of readers (behind a barrier).
+template <int TM, int EPI>
+__device__ __forceinline__ void lin_epilogue(const LinK& g, f32x16 (&acc)[TM], float* smem, int bz, int m0, int tm_eff, int wave, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int col = wave * 32 + l31;
+    if (EPI == EPI_PLAIN) {
+        if (col < g.N) {
+            const float bj = g.bias ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+            float* c0 = g.C + (long)bz * g.c_batch + col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (i < tm_eff && row < g.M) {   // (a 32-row tile owns only its first row block)
+                        float v = acc[i][r] + bj;
+                        if (g.act == 1) v = as_relu(v);
+                        else if (g.act == 2) v = as_sigmoid(v);
+                        c0[(long)row * g.ldc] = v;
+                    }
+                }
+        }
+        return;
+    }
+    const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    constexpr float inv_d = 1.0f / BN;
+    // backward: everything this wave reads from global memory (x_hat rows, rstd, mask words of its 4 rows per 32-row
+    // block) is requested up front -- vector memory operations retire in order, so a load issued behind the first block's
+    // stores would wait for them
+    // (rstd and the mask words are wave-uniform: scalar loads, which do not queue behind the vector stores)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float h[TM][4][4];
+    if (EPI == EPI_LNB) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long row = min((long)m0 + i * 32 + wave_u + 8 * q, (long)g.M - 1);
+                const float* xr = g.xhat + (long)bz * g.x_batch + row * g.ldx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[i][q][c] = xr[lane + 64 * c];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {   // 32 rows at a time through 32 KB of LDS
+        if (i >= tm_eff) break;
+        if (i > 0) lds_barrier();    // the previous block's rows are all read
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[i][r] + bj;
+            if (EPI == EPI_LNF) v = as_relu(v);
+            smem[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // one wave per row; lane holds features lane + 64 c
+            const int rr = wave_u + 8 * q;
+            const long row = m0 + i * 32 + rr;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = smem[rr * BN + lane + 64 * c];
+            float* o = g.C + (long)bz * g.c_batch + row * g.ldc;
+            if (EPI == EPI_LNF) {
+                unsigned long long pos[4];
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s += v[c];
+                    pos[c] = __ballot(v[c] > 0.f);
+                }
+                const float mean = wave_sum(s) * inv_d;
+                float qq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] -= mean;
+                    qq += v[c] * v[c];
+                }
+                const float rs = 1.0f / sqrtf(wave_sum(qq) * inv_d + g.eps);
+                if (row < g.M) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[lane + 64 * c] = v[c] * rs;
+                    if (lane == 0) g.rstd[row * g.batch + bz] = rs;
+                    if (lane < 4) g.bits[(row * g.batch + bz) * 4 + lane] = lane == 0 ? pos[0] : lane == 1 ? pos[1] : lane == 2 ? pos[2] : pos[3];
+                }
+            } else {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s1 += v[c];
+                    s2 += v[c] * h[i][q][c];
+                }
+                const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+                if (row < g.M) {
+                    const float rs = g.rstd_in[row * g.batch + bz];
+                    const unsigned long long* mw = g.bits_in + (row * g.batch + bz) * 4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float d = rs * (v[c] - m1 - h[i][q][c] * m2);
+                        o[lane + 64 * c] = (mw[c] >> lane) & 1ull ? d : 0.f;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // NB ring slots: 3 (two k-tiles in flight, 60 KB: two workgroups per CU) or 2 (one in flight, 40 KB: three per CU; diagnostic)
@@ -280,112 +389,202 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
         return;
     }
 
-    // ---- epilogue.  D[row][col]: col = wave * 32 + l31, row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh
-    const int col = wave * 32 + l31;
-    if (EPI == EPI_PLAIN) {
-        if (col < g.N) {
-            const float bj = g.bias ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
-            float* c0 = g.C + (long)bz * g.c_batch + col;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (i < tm_eff && row < g.M) {   // (a 32-row tile owns only its first row block)
-                        float v = acc[i][r] + bj;
-                        if (g.act == 1) v = as_relu(v);
-                        else if (g.act == 2) v = as_sigmoid(v);
-                        c0[(long)row * g.ldc] = v;
-                    }
-                }
-        }
-        return;
-    }
-    const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
-    constexpr float inv_d = 1.0f / BN;
-    // backward: everything this wave reads from global memory (x_hat rows, rstd, mask words of its 4 rows per 32-row
-    // block) is requested up front -- vector memory operations retire in order, so a load issued behind the first block's
-    // stores would wait for them
-    // (rstd and the mask words are wave-uniform: scalar loads, which do not queue behind the vector stores)
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    float h[TM][4][4];
-    if (EPI == EPI_LNB) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long row = min((long)m0 + i * 32 + wave_u + 8 * q, (long)g.M - 1);
-                const float* xr = g.xhat + (long)bz * g.x_batch + row * g.ldx;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) h[i][q][c] = xr[lane + 64 * c];
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {   // 32 rows at a time through 32 KB of LDS
-        if (i >= tm_eff) break;
-        if (i > 0) lds_barrier();    // the previous block's rows are all read
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[i][r] + bj;
-            if (EPI == EPI_LNF) v = as_relu(v);
-            smem[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = v;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // one wave per row; lane holds features lane + 64 c
-            const int rr = wave_u + 8 * q;
-            const long row = m0 + i * 32 + rr;
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = smem[rr * BN + lane + 64 * c];
-            float* o = g.C + (long)bz * g.c_batch + row * g.ldc;
-            if (EPI == EPI_LNF) {
-                unsigned long long pos[4];
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s += v[c];
-                    pos[c] = __ballot(v[c] > 0.f);
-                }
-                const float mean = wave_sum(s) * inv_d;
-                float qq = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    v[c] -= mean;
-                    qq += v[c] * v[c];
-                }
-                const float rs = 1.0f / sqrtf(wave_sum(qq) * inv_d + g.eps);
-                if (row < g.M) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[lane + 64 * c] = v[c] * rs;
-                    if (lane == 0) g.rstd[row * g.batch + bz] = rs;
-                    if (lane < 4) g.bits[(row * g.batch + bz) * 4 + lane] = lane == 0 ? pos[0] : lane == 1 ? pos[1] : lane == 2 ? pos[2] : pos[3];
-                }
-            } else {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s1 += v[c];
-                    s2 += v[c] * h[i][q][c];
-                }
-                const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
-                if (row < g.M) {
-                    const float rs = g.rstd_in[row * g.batch + bz];
-                    const unsigned long long* mw = g.bits_in + (row * g.batch + bz) * 4;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float d = rs * (v[c] - m1 - h[i][q][c] * m2);
-                        o[lane + 64 * c] = (mw[c] >> lane) & 1ull ? d : 0.f;
-                    }
-                }
-            }
-        }
-    }
+    lin_epilogue<TM, EPI>(g, acc, smem, bz, m0, tm_eff, wave, lane);
     if (stamp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         g.dbg[8L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
         g.dbg[8L * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layers with the products on the bfloat16 matrix instruction (v_mfma_f32_32x32x16_bf16: 16 x the rate of
+// v_mfma_f32_32x32x2_f32), fp32 in, fp32 out, fp32 accumulation.  An fp32 number is EXACTLY the sum of three bfloat16
+// numbers (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 8 + 8 + 8 significand bits), so a product a.b is the
+// sum of nine plane products with exact operands; the three smallest (lo.lo, lo.mid, mid.lo, each <= 2^-24 |a||b|) are
+// dropped: six MFMAs per 16-deep k-step.  Against an fp64 product of the same fp32 operands this is MORE accurate than the
+// fp32 matrix instruction (rms 2.4e-7 vs 2.9e-7 of rms C: the bf16 instruction adds 16 products before it rounds, the fp32
+// one two; tools/bench_split_gemm.py, tests/test_gpu_parity.py::test_split_matrix_arithmetic_*).
+//   * B (the folded weights) arrives as planes, emitted once per step by as_emit_planes (rowops.hip) k-step-major:
+//     [plane][head][K / 16][rows][16] bf16, so that the fragment of a wave (32 columns x 8 k x 2 lane halves) is 1 KiB of
+//     consecutive bytes.  A wave's columns are its own: B fragments go from L2 straight to registers (global_load_dwordx4,
+//     two k-steps ahead in three name-rotated register sets), not through the LDS.
+//   * A (activations / gradients) stays fp32 in HBM.  Each thread loads 4 consecutive k of one row per 32-deep k-tile (two
+//     tiles ahead), splits them (v_cvt_pk_bf16_f32 + v_pk_add_f32: 4.5 vector instructions per element, once per workgroup)
+//     and writes 3 x 8 bytes into the plane image of the tile in LDS ([plane][64 rows][32 k] bf16, the four 16-byte chunks
+//     of a row XOR-swizzled by (row >> 1) & 3: a ds_read_b128 of 8 consecutive rows touches every bank once).  All eight
+//     waves read their A fragments from there: one barrier per 32-deep k-tile, two plane images (24 KB).
+//   * accumulator layout = that of the fp32 instruction: the LayerNorm epilogues above are shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 numbers -> three words of packed bfloat16 pairs (element a in the low half)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v.x -= __uint_as_float(hi << 16);
+    v.y -= __uint_as_float(hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v.x -= __uint_as_float(mid << 16);
+    v.y -= __uint_as_float(mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// a pointer the compiler must treat as wave-uniform (SGPR pair): base of the scalar-base form of a global load, whose lane
+// part is then a 32-bit byte offset.  (Without it hipcc re-associates base + lane offset into a loop-invariant 64-bit VECTOR
+// address and adds the uniform per-step part to that: two address registers and a 64-bit vector add per load.)
+typedef const __attribute__((address_space(1))) char* gptr;   // global address space (the integer round trip would lose it: flat loads)
+__device__ __forceinline__ gptr uniform_ptr(const void* p) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<gptr>(((uintptr_t)hi << 32) | lo);
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
+typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
+
+constexpr int S6_BK = 32;                 // k-tile of the A image (two MFMA k-steps)
+constexpr int S6_PLANE = 64 * S6_BK * 2;  // bytes of one plane of one k-tile: 64 rows x 32 bf16
+constexpr int S6_BUF = 3 * S6_PLANE;
+
+template <int N> struct IC { static constexpr int value = N; };
+
+// The main loop shared by the 256-column kernel (NW = 8 waves) and the output layer's (NW = 4): 64 rows x 32 NW columns,
+// wave w = columns 32 w .. 32 w + 31 of all 64 rows (two accumulators).  `sm`: 2 x S6_BUF bytes.
+//   A / lda: first row of the tile's operand rows (row index clamped to rows_valid - 1), k >= ka_valid reads as zero
+//   bp (wave-uniform) + b_lane bytes: this lane's B fragment of plane 0, k-step 0; plane stride bp_plane, k-step stride bp_step (elements)
+//   (rows of A within 2^31 bytes of the tile's first: lda < 2^23 floats)
+template <int NW, int TME>   // TME: row blocks of 32 the tile really has (a 32-row tile multiplies only the first)
+__device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm, const float* __restrict__ A, long lda, int rows_valid,
+                                             int K, int ka_valid, const uint16_t* __restrict__ bp, unsigned b_lane, long bp_plane,
+                                             long bp_step, int tid, int lane) {
+    constexpr int NTH = NW * 64;
+    constexpr int AL = 512 / NTH;         // float4 loads per thread and k-tile (64 rows x 8 chunks of 4 k)
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_chunk = tid & 7;
+    // every global access = wave-uniform base pointer + 32-bit lane offset (the scalar-base form of global_load: no 64-bit
+    // vector address arithmetic, no address register pairs)
+    unsigned a_off[AL];
+    int a_wr[AL];
+#pragma unroll
+    for (int q = 0; q < AL; ++q) {
+        const int row = (tid >> 3) + q * (NTH / 8);
+        a_off[q] = (unsigned)(min(row, rows_valid - 1) * (int)lda + a_chunk * 4) * 4u;   // bytes
+        a_wr[q] = row * 64 + (((a_chunk >> 1) ^ ((row >> 1) & 3)) * 16) + (a_chunk & 1) * 8;
+    }
+    const int nk = K / S6_BK, nj = 2 * nk;
+    const gptr Au = uniform_ptr(A);
+    // every load below is unconditional (indices clamped to the last tile / k-step): straight-line code, so that hipcc's
+    // s_waitcnt vmcnt counts are exact -- a load under a branch makes every later wait assume the branch was not taken,
+    // i.e. wait for (nearly) everything in flight
+    auto a_load = [&](f32x4 (&dst)[AL], int kt) {
+        kt = min(kt, nk - 1);
+        // chunks at or beyond ka_valid (a reduction padded up to the tile whose B rows there are zero planes) re-read chunk 0
+        // of the row: an ADDRESS select -- a value select would put the load itself under a branch
+        // (the offset stays non-negative: it is zero-extended by the scalar-base form)
+        const unsigned ko = kt * S6_BK + a_chunk * 4 + 4 <= ka_valid ? (unsigned)(kt * S6_BK) * 4u : 0u - (unsigned)a_chunk * 16u;
+#pragma unroll
+        for (int q = 0; q < AL; ++q) dst[q] = *reinterpret_cast<gptr_f4>(Au + (a_off[q] + ko));
+    };
+    auto a_store = [&](const f32x4 (&src)[AL], int buf) {
+#pragma unroll
+        for (int q = 0; q < AL; ++q) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(src[q].x, src[q].y, h0, m0, l0);
+            split_pair(src[q].z, src[q].w, h1, m1, l1);
+            unsigned char* d = sm + buf * S6_BUF + a_wr[q];
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + S6_PLANE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * S6_PLANE) = make_uint2(l0, l1);
+        }
+    };
+    auto b_load = [&](u32x4 (&dst)[3], int j) {
+        j = min(j, nj - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<gptr_u4>(uniform_ptr(bp + p * bp_plane + j * bp_step) + b_lane);
+    };
+    const int sw = (l31 >> 1) & 3;        // rows i * 32 + l31 share it (32 = 0 mod 8)
+    const unsigned char* a_rd = sm + l31 * 64;
+
+    f32x4 aq[3][AL];
+    u32x4 bq[3][3];
+    a_load(aq[0], 0);
+    a_load(aq[1], 1);
+    b_load(bq[0], 0);
+    b_load(bq[1], 1);
+    a_store(aq[0], 0);
+    lds_barrier();
+    // k-tile kt (kt % 3 == U): its plane image is in buffer kt & 1, its B fragments in sets (2 kt) % 3 and (2 kt + 1) % 3
+    auto tile = [&](auto Uc, int kt) {
+        constexpr int U = decltype(Uc)::value;
+        const unsigned char* img = a_rd + (kt & 1) * S6_BUF;
+        a_load(aq[(U + 2) % 3], kt + 2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            b_load(bq[(2 * U + s + 2) % 3], 2 * kt + s + 2);
+            __builtin_amdgcn_sched_barrier(0);   // the look-ahead loads stay HERE, two k-steps in front of their first use
+            bf16x8 fa[TME][3];
+#pragma unroll
+            for (int i = 0; i < TME; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fa[i][p] = *reinterpret_cast<const bf16x8*>(img + p * S6_PLANE + i * 32 * 64 + (((2 * s + lh) ^ sw) * 16));
+            const u32x4(&bs)[3] = bq[(2 * U + s) % 3];
+            bf16x8 fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[p] = __builtin_bit_cast(bf16x8, bs[p]);
+            // six of the nine plane products, smallest first: mid.mid, lo.hi, hi.lo, mid.hi, hi.mid, hi.hi
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int o = 0; o < 6; ++o)
+#pragma unroll
+                for (int i = 0; i < TME; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[PB[o]], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a_store(aq[(U + 1) % 3], (kt & 1) ^ 1);   // (behind the last tile: a clamped repeat into the idle buffer)
+        lds_barrier();
+    };
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        tile(IC<0>{}, kt);
+        tile(IC<1>{}, kt + 1);
+        tile(IC<2>{}, kt + 2);
+    }
+    if (kt < nk) tile(IC<0>{}, kt);
+    if (kt + 1 < nk) tile(IC<1>{}, kt + 1);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT, 4) void lin_s6_kernel(LinK g) {
+    constexpr int EPIT = 32 * BN;
+    static_assert(EPIT * 4 >= 2 * S6_BUF, "the epilogue's staging area holds both plane images");
+    __shared__ __attribute__((aligned(16))) float smem[EPIT];
+    int bz, m0, tm_eff;
+    if ((int)blockIdx.x < g.n_big) {
+        bz = blockIdx.x / g.big_per_batch;
+        m0 = (blockIdx.x - bz * g.big_per_batch) * 64;
+        tm_eff = 2;
+    } else {
+        const int j = blockIdx.x - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        tm_eff = 1;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const uint16_t* bp = g.Bp + (long)bz * g.bp_batch;
+    const unsigned b_lane = (unsigned)((wave * 32 + (lane & 31)) * 16 + (lane >> 5) * 8) * 2u;   // bytes
+    unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+    const float* A = g.A + (long)bz * g.a_batch + (long)m0 * g.lda;
+    if (tm_eff == 2) s6_main_loop<8, 2>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane);
+    else s6_main_loop<8, 1>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane);
+    lin_epilogue<2, EPI>(g, acc, smem, bz, m0, tm_eff, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -608,6 +807,11 @@ int launch(const LinK& k, hipStream_t st) {
     kk.small_per_batch = as_cdiv(rest, 32);
     const long total = (long)kk.n_big + (long)kk.small_per_batch * k.batch;
     if (kk.small_per_batch == 0) kk.small_per_batch = 1;
+    if (kk.Bp) {   // the products on the bf16 matrix instruction, B as planes (lin_s6_kernel)
+        hipLaunchKernelGGL((lin_s6_kernel<EPI>), dim3((unsigned)total), dim3(NT), 0, st, kk);
+        AS_LAUNCH_CHECK("as_lin_s6");
+        return 0;
+    }
 #ifdef AS_DIAG
     if (nbuf == 2) hipLaunchKernelGGL((lin_f32_kernel<64, B_KC, EPI, 2>), dim3((unsigned)total), dim3(NT), 0, st, kk);
     else
@@ -658,6 +862,11 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     k.rstd = a->rstd; k.bits = a->bits;
     k.xhat = a->xhat; k.ldx = a->ldx; k.x_batch = a->x_batch; k.rstd_in = a->rstd_in; k.bits_in = a->bits_in;
     if (k.ka_valid % 4) return 0;
+    // B as bfloat16 planes (as_emit_planes) and the split arithmetic on: the bf16-MFMA kernel; else the exact fp32 one
+    if (a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= BN && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
+        a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0) {
+        k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
+    }
     if (a->epi == EPI_LNF) {
         if (!a->rstd || !a->bits || !a->b_kc) return 0;
         return launch<true, EPI_LNF>(k, st) == 0 ? 1 : -1;

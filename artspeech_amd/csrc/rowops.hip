@@ -4,6 +4,7 @@
 // LayerNorm affine parameters, per-token segment sums (embedding / layer-0 input-projection
 // gradients), gather, sigmoid backward and the flat Adam update.  All HBM-bound: one wave per row,
 // coalesced 4-byte or 16-byte lanes, wave shuffles for the row reductions.
+#include "gemm_internal.h"
 #include "rowops.h"
 
 namespace {
@@ -151,6 +152,56 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, 
     }
     s = as_wave_sum(s);
     if (lane == 0) bf[row] = b[row] + s;
+}
+
+// ---- a weight matrix as three bfloat16 planes for the split-arithmetic kernels (lin_f32.hip, lin_s6_kernel):
+// x = hi + mid + lo exactly (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even),
+// out[plane][batch][Kpad / 16][rows_pad][16]: the 32 bytes a row contributes to a 16-deep k-step are one sector, and the
+// rows of a k-step are consecutive (the B fragment of a wave = 1 KiB).  One thread per (batch, k-step, row).
+struct PlanesJobs { as_planes_job j[8]; long first[9]; };
+
+__global__ __launch_bounds__(256) void emit_planes_kernel(PlanesJobs jobs, int n_jobs) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= jobs.first[n_jobs]) return;
+    int q = 0;
+    while (q + 1 < n_jobs && gid >= jobs.first[q + 1]) ++q;
+    const as_planes_job& J = jobs.j[q];
+    long r = gid - jobs.first[q];
+    const int n = (int)(r % J.rows_pad);
+    r /= J.rows_pad;
+    const int nks = J.Kpad / 16;
+    const int ks = (int)(r % nks), b = (int)(r / nks);
+    unsigned hi[8], mid[8], lo[8];
+    const float* src = J.B + (long)b * J.batch_stride + (long)n * J.n_stride;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = ks * 16 + 2 * e;
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[h] = (n < J.N && k + h < J.K) ? src[(long)(k + h) * J.k_stride] : 0.f;
+        unsigned short p[3][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float x = v[h];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const __bf16 t = (__bf16)x;                       // round to nearest even
+                p[pl][h] = __builtin_bit_cast(unsigned short, t);
+                x -= (float)t;                                    // exact
+            }
+        }
+        hi[e] = p[0][0] | ((unsigned)p[0][1] << 16);
+        mid[e] = p[1][0] | ((unsigned)p[1][1] << 16);
+        lo[e] = p[2][0] | ((unsigned)p[2][1] << 16);
+    }
+    const long bstride = (long)nks * J.rows_pad * 16, pstride = (long)J.batch * bstride;
+    uint16_t* o = J.out + (long)b * bstride + ((long)ks * J.rows_pad + n) * 16;
+    uint4* o0 = reinterpret_cast<uint4*>(o);
+    uint4* o1 = reinterpret_cast<uint4*>(o + pstride);
+    uint4* o2 = reinterpret_cast<uint4*>(o + 2 * pstride);
+    o0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);   o0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    o1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); o1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+    o2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);   o2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 
 // ---- unfold: dW[n][k] = dWf[n][k] * gamma[k] + dbf[n] * beta[k] ; dgamma[k] = sum_n dWf[n][k] W[n][k] ;
@@ -882,6 +933,23 @@ int as_fold(const float* W, const float* gamma, const float* beta, const float* 
     const long total = (long)heads * Rpad;
     hipLaunchKernelGGL(fold_kernel, dim3(as_cdiv(total, 4)), dim3(256), 0, st, W, gamma, beta, b, Wf, bf, total, R, K, Rpad);
     AS_LAUNCH_CHECK("fold");
+    return 0;
+}
+int as_emit_planes(const as_planes_job* jobs, int n, hipStream_t st) {
+    AS_REQUIRE(jobs && n >= 1 && n <= 8, AS_ERR_BAD_ARG, "as_emit_planes: 1..8 jobs");
+    PlanesJobs pj{};
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const as_planes_job& J = jobs[i];
+        AS_REQUIRE(J.B && J.out && J.batch > 0 && J.N > 0 && J.K > 0 && J.rows_pad >= J.N && J.Kpad >= J.K && J.Kpad % 16 == 0 &&
+                   (reinterpret_cast<uintptr_t>(J.out) & 15) == 0, AS_ERR_BAD_ARG, "as_emit_planes: bad job %d", i);
+        pj.j[i] = J;
+        pj.first[i] = total;
+        total += (long)J.batch * (J.Kpad / 16) * J.rows_pad;
+    }
+    pj.first[n] = total;
+    hipLaunchKernelGGL(emit_planes_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, st, pj, n);
+    AS_LAUNCH_CHECK("emit_planes");
     return 0;
 }
 int as_unfold(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,

@@ -140,6 +140,18 @@ int as_artspeech_dw2(const as_dims* dims, const float* params, int32_t B, int32_
  * capturing).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
 void as_set_overlap(int32_t on);
 
+/* How the library forms fp32 matrix products (every nn.Linear / weight gradient of the path; the reference computes them
+ * in fp32: encoder_decoder/models.py:10-33, transformer/models.py:37-100):
+ *   0  v_mfma_f32_32x32x2_f32 on the fp32 operands (the exact fp32 matrix instruction);
+ *   1  (default) each fp32 operand is split EXACTLY into three bfloat16 numbers (8 + 8 + 8 significand bits) and the
+ *      product is rebuilt from six of the nine plane products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
+ *      three dropped ones are each <= 2^-24 |a||b|.  Inputs, outputs and accumulation stay fp32; against an fp64 product
+ *      of the same operands the result is at least as accurate as mode 0 (tests/test_gpu_parity.py::test_split_arith_*).
+ *      Kernels without such a path use mode 0.  Inf operands give NaN (inf - inf in the split) where mode 0 gives inf.
+ * Process-wide; read at launch time.  Env ARTSPEECH_MATRIX_ARITH=fp32|bf16x6 sets the initial value. */
+void as_set_matrix_arith(int32_t mode);
+int32_t as_get_matrix_arith(void);
+
 /* Data-parallel hook: make `waiting_stream` wait until the most recent as_artspeech_bwd enqueued on `compute_stream` (same
  * device) has finished the gradients of the trunk Linear and of all heads, i.e. the tail [layout.lin_w, layout.total) of
  * the flat gradient buffer (74 % of the parameters) -- their all-reduce can then run while the GRU backward recurrences
