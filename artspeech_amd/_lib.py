@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libartspeech_hip.so")
 # product library has none of them compiled in, so AS_* environment variables cannot change what it computes.
 if os.environ.get("ARTSPEECH_DIAG_LIB") == "1":
     LIB_PATH = os.path.join(_HERE, "libartspeech_hip_diag.so")
+elif os.environ.get("ARTSPEECH_DIAG_LIB"):   # a diagnostic flavour built with extra defines (build.py --suffix=...)
+    LIB_PATH = os.path.abspath(os.environ["ARTSPEECH_DIAG_LIB"])
 
 c_f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 

@@ -44,10 +44,16 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(s) > t for s in (src, *extra))
 
 
-def build(force=False, verbose=True, diag=False):
+def build(force=False, verbose=True, diag=False, defines=(), suffix=""):
+    """defines / suffix (diagnostic flavour only): extra -D macros (compile-time ablations such as AS_S6_ABL=2) and a name
+    suffix for the library and its object directory, e.g. libartspeech_hip_diag_abl2.so (ARTSPEECH_DIAG_LIB=<path> loads it)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     OBJ, LIB = (OBJ_DIAG, LIB_DIAG) if diag else (globals()["OBJ"], globals()["LIB"])
     COMMON = globals()["COMMON"] + (["-DAS_DIAG"] if diag else [])
+    if defines or suffix:
+        assert diag, "extra defines are for the diagnostic flavour"
+        COMMON += [f"-D{d}" for d in defines]
+        OBJ, LIB = OBJ + suffix, LIB.replace(".so", suffix + ".so")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "artspeech_hip.h"))
@@ -73,4 +79,6 @@ def build(force=False, verbose=True, diag=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    sfx = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv, defines=defs, suffix=sfx))

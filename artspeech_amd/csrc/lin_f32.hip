@@ -411,8 +411,9 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
 //     two k-steps ahead in three name-rotated register sets), not through the LDS.
 //   * A (activations / gradients) stays fp32 in HBM.  Each thread loads 4 consecutive k of one row per 32-deep k-tile (two
 //     tiles ahead), splits them (v_cvt_pk_bf16_f32 + v_pk_add_f32: 4.5 vector instructions per element, once per workgroup)
-//     and writes 3 x 8 bytes into the plane image of the tile in LDS ([plane][64 rows][32 k] bf16, the four 16-byte chunks
-//     of a row XOR-swizzled by (row >> 1) & 3: a ds_read_b128 of 8 consecutive rows touches every bank once).  All eight
+//     and writes 3 x 8 bytes into the plane image of the tile in LDS ([plane][64 rows][32 k] bf16 = 64-byte rows, the four
+//     16-byte chunks of a row XOR-swizzled by (row >> 2) & 3: the 16 lanes a ds_read_b128 serves per LDS cycle -- rows
+//     {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} -- then touch each of the 64 banks once).  All eight
 //     waves read their A fragments from there: one barrier per 32-deep k-tile, two plane images (24 KB).
 //   * accumulator layout = that of the fp32 instruction: the LayerNorm epilogues above are shared.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -459,7 +460,15 @@ template <int N> struct IC { static constexpr int value = N; };
 template <int NW, int TME>   // TME: row blocks of 32 the tile really has (a 32-row tile multiplies only the first)
 __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm, const float* __restrict__ A, long lda, int rows_valid,
                                              int K, int ka_valid, const uint16_t* __restrict__ bp, unsigned b_lane, long bp_plane,
-                                             long bp_step, int tid, int lane) {
+                                             long bp_step, int tid, int lane, bool late, unsigned long long* stamp1 = nullptr) {
+    // compile-time ablations of a diagnostic build (python -m artspeech_amd.build --diag -DAS_S6_ABL=n): 1 = no epilogue,
+    // 2 = no B loads inside the loop, 3 = no A loads / splits / LDS stores inside the loop, 4 = no MFMAs, 5 = every tile reads
+    // the fragments of plane image 0.  (A run-time switch here costs the loop its register arrays: 16 x slower.)
+#ifdef AS_S6_ABL
+    constexpr int abl = AS_S6_ABL;
+#else
+    constexpr int abl = 0;
+#endif
     constexpr int NTH = NW * 64;
     constexpr int AL = 512 / NTH;         // float4 loads per thread and k-tile (64 rows x 8 chunks of 4 k)
     const int l31 = lane & 31, lh = lane >> 5;
@@ -472,7 +481,7 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
     for (int q = 0; q < AL; ++q) {
         const int row = (tid >> 3) + q * (NTH / 8);
         a_off[q] = (unsigned)(min(row, rows_valid - 1) * (int)lda + a_chunk * 4) * 4u;   // bytes
-        a_wr[q] = row * 64 + (((a_chunk >> 1) ^ ((row >> 1) & 3)) * 16) + (a_chunk & 1) * 8;
+        a_wr[q] = row * 64 + (((a_chunk >> 1) ^ ((row >> 2) & 3)) * 16) + (a_chunk & 1) * 8;
     }
     const int nk = K / S6_BK, nj = 2 * nk;
     const gptr Au = uniform_ptr(A);
@@ -505,7 +514,7 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
 #pragma unroll
         for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<gptr_u4>(uniform_ptr(bp + p * bp_plane + j * bp_step) + b_lane);
     };
-    const int sw = (l31 >> 1) & 3;        // rows i * 32 + l31 share it (32 = 0 mod 8)
+    const int sw = (l31 >> 2) & 3;        // rows i * 32 + l31 share it (32 = 0 mod 16)
     const unsigned char* a_rd = sm + l31 * 64;
 
     f32x4 aq[3][AL];
@@ -516,34 +525,43 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
     b_load(bq[1], 1);
     a_store(aq[0], 0);
     lds_barrier();
+    if (stamp1) *stamp1 = __builtin_amdgcn_s_memtime();
     // k-tile kt (kt % 3 == U): its plane image is in buffer kt & 1, its B fragments in sets (2 kt) % 3 and (2 kt + 1) % 3
     auto tile = [&](auto Uc, int kt) {
         constexpr int U = decltype(Uc)::value;
-        const unsigned char* img = a_rd + (kt & 1) * S6_BUF;
-        a_load(aq[(U + 2) % 3], kt + 2);
+        const unsigned char* img = a_rd + (abl == 5 ? 0 : (kt & 1) * S6_BUF);
+        if (abl != 3) a_load(aq[(U + 2) % 3], kt + 2);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            b_load(bq[(2 * U + s + 2) % 3], 2 * kt + s + 2);
+            if (abl != 2) b_load(bq[(2 * U + s + 2) % 3], 2 * kt + s + 2);
             __builtin_amdgcn_sched_barrier(0);   // the look-ahead loads stay HERE, two k-steps in front of their first use
             bf16x8 fa[TME][3];
 #pragma unroll
-            for (int i = 0; i < TME; ++i)
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int i = 0; i < TME; ++i)
                     fa[i][p] = *reinterpret_cast<const bf16x8*>(img + p * S6_PLANE + i * 32 * 64 + (((2 * s + lh) ^ sw) * 16));
             const u32x4(&bs)[3] = bq[(2 * U + s) % 3];
             bf16x8 fb[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fb[p] = __builtin_bit_cast(bf16x8, bs[p]);
-            // six of the nine plane products, smallest first: mid.mid, lo.hi, hi.lo, mid.hi, hi.mid, hi.hi
-            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+            // six of the nine plane products (without mid.lo, lo.mid, lo.lo).  Those with the hi plane of A first: the first six
+            // MFMAs need two of the six LDS reads, the mid / lo fragments arrive under them.  (The order does not matter to the
+            // result's error: the accumulator already holds the sum of the earlier k-steps.)
+            constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
             for (int o = 0; o < 6; ++o)
 #pragma unroll
-                for (int i = 0; i < TME; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[PB[o]], acc[i], 0, 0, 0);
+                for (int i = 0; i < TME; ++i)
+                    if (abl != 4) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[PB[o]], acc[i], 0, 0, 0);
+                    else acc[i][o] += (float)fa[i][PA[o]][0] * (float)fb[PB[o]][0];
             __builtin_amdgcn_sched_barrier(0);
+            // The split of the NEXT tile (vector + LDS-store work, no matrix work) sits at a different place in the two halves of
+            // the workgroup: waves 0-3 behind the tile's second k-step, waves 4-7 between the two.  Waves w and w + 4 share a
+            // SIMD and, running the same program between the same barriers, would otherwise do their vector work at the same
+            // moment and their matrix work at the same moment -- the matrix pipe idles through the former.
+            if (abl != 3 && late == (s == 0)) a_store(aq[(U + 1) % 3], (kt & 1) ^ 1);   // (behind the last tile: a clamped repeat)
         }
-        a_store(aq[(U + 1) % 3], (kt & 1) ^ 1);   // (behind the last tile: a clamped repeat into the idle buffer)
         lds_barrier();
     };
     int kt = 0;
@@ -582,9 +600,32 @@ __global__ __launch_bounds__(NT, 4) void lin_s6_kernel(LinK g) {
     const unsigned b_lane = (unsigned)((wave * 32 + (lane & 31)) * 16 + (lane >> 5) * 8) * 2u;   // bytes
     unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
     const float* A = g.A + (long)bz * g.a_batch + (long)m0 * g.lda;
-    if (tm_eff == 2) s6_main_loop<8, 2>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane);
-    else s6_main_loop<8, 1>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane);
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool stamp = g.dbg != nullptr && tid == 0 && blockIdx.x < g.dbg_max;   // diagnostic cycle stamps (as_lin_debug_stamps)
+    unsigned long long* d = stamp ? g.dbg + 8L * blockIdx.x : nullptr;
+    if (stamp) {
+        d[0] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_memrealtime();
+        d[5] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20) << 32);
+    }
+    // diagnostic (AS_LIN_STAGGER = n > 0): the workgroups of the second fill (blocks 256..511 under round-robin dispatch, the
+    // second tenant of each CU) start n x 1024 cycles late, so that the two tenants' epilogues (and the chip's store bursts)
+    // do not coincide; n < 0: the same for blocks whose CU-slot parity ... (see lin_f32_kernel)
+    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    if (tm_eff == 2) s6_main_loop<8, 2>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane, late, stamp ? d + 1 : nullptr);
+    else s6_main_loop<8, 1>(acc, sm, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane, late, stamp ? d + 1 : nullptr);
+    if (stamp) d[2] = __builtin_amdgcn_s_memtime();
+#if defined(AS_S6_ABL) && AS_S6_ABL == 1
+    if (acc[0][0] == 123.456f) g.C[0] = acc[0][0] + acc[1][0];  // keep the loop alive
+    return;
+#endif
     lin_epilogue<2, EPI>(g, acc, smem, bz, m0, tm_eff, wave, lane);
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[6] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ L.as_lin_debug_stamps(None, 0)
 s = stamps.cpu().numpy().reshape(nwg, 8).astype(np.int64)
 pro, loop, epi, tot = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 3] - s[:, 0]
 r0 = s[:, 4].min()
+r0 = s[s[:, 3] > 0, 4].min()
 start_us, end_us = (s[:, 4] - r0) / 100.0, (s[:, 6] - r0) / 100.0     # s_memrealtime: 100 MHz, one clock for the chip
 print("per workgroup, shader cycles (s_memtime differences) and wall microseconds (s_memrealtime), launch order")
 live = s[:, 3] > 0
@@ -46,5 +47,6 @@ for lo in range(0, nwg, 256):
           f"loop {np.median(loop[sl]):8.0f}  epilogue {np.median(epi[sl]):7.0f}  total {np.median(tot[sl]):8.0f} cycles")
 print(f"launch: {end_us.max():.1f} us from first start to last end; clock = {np.median(tot / np.maximum(end_us - start_us, 1e-3)):.0f} cycles/us")
 # how many workgroups are in flight over time
+start_us, end_us = start_us[live], end_us[live]
 ts = np.linspace(0, end_us.max(), 25)
 print("in flight:", [int(((start_us <= t) & (end_us > t)).sum()) for t in ts])
