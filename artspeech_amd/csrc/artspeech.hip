@@ -15,6 +15,7 @@
 //    writes sigmoid(.) straight into the (B, T, A, 2, N) output (:141-145).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -41,7 +42,7 @@ struct HeadWs {  // offsets in floats relative to the head workspace base
     int64_t dpre3, dz2, dz1, dxhat, dw1f, dw2f, dw3f, slab, slab2, slab3, bits1, bits2, lpart, lpart_n, total;
     // the folded weights as bfloat16 planes (as_emit_planes): forward orientation [rows = out features][k = in features] and,
     // for the input-gradient chain, transposed [rows = in features][k = out features]
-    int64_t w1p, w2p, w3p, w2tp, w3tp;
+    int64_t w1p, w2p, w3p, w2tp, w3tp, w1tp;
 };
 constexpr int OUT_BN = 128;   // column tile of the output layer's kernel (lin_out): rows of the W3' planes per head
 
@@ -85,12 +86,16 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.w3p = c.take(as_planes_floats((int)A, (int)as_round_up(O, OUT_BN), D));
     w.w2tp = c.take(as_planes_floats((int)A, D, D));
     w.w3tp = c.take(as_planes_floats((int)A, D, Opad));
+    w.w1tp = c.take(as_planes_floats(1, (int)as_round_up(H, 128), (int)(A * D)));   // d(x_hat) = dz1 . W1': rows = the H inputs, k = (head, feature)
     w.total = c.off;
     return w;
 }
 
 struct ModelWs {
     int64_t tokflag, tab0, y0, y0d, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
+    // GRU layer-1 input weights as bfloat16 planes (as_emit_planes)
+    int64_t wih1p;
+    int xp_bn;   // column block of the layer-1 input projection on the split-arithmetic kernel (256 | 128; 0 = not a case)
 };
 
 ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
@@ -113,6 +118,11 @@ ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
         w.dgi0 = c.take(R * 6 * H);
         w.dgh0 = c.take(R * 6 * H);
         w.dtab0 = c.take(V * 6 * H);
+        // split-arithmetic GEMMs of the GRU side (H % 16 == 0: reductions of 2H and 6H in whole 32-deep k-tiles; 2H <= 256 columns)
+        w.xp_bn = (H % 16 == 0 && 2 * H <= 256) ? ((6 * H) % 256 == 0 ? 256 : ((6 * H) % 128 == 0 ? 128 : 0)) : 0;
+        if (w.xp_bn) {
+            w.wih1p = c.take(as_planes_floats((int)(6 * H / w.xp_bn), w.xp_bn, (int)(2 * H)));
+        }
     } else {
         w.tab0 = c.take(V * H);   // relu(Emb Wl^T + bl) per token
         w.dtab0 = c.take(V * H);
@@ -182,14 +192,15 @@ int head_fold(const as_dims& d, const as_layout& L, const float* P, int64_t rows
         // the input-gradient chain (d(x_hat) = dz . W': the reduction runs over W' rows)
         const int Opad = (int)as_round_up(O, 32), Hp = (int)as_round_up(H, 32);
         auto up = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
-        as_planes_job j[5] = {
+        as_planes_job j[6] = {
             {ws + w.w1f, H, 1, (long)D * H, A, D, H, D, Hp, up(w.w1p)},
             {ws + w.w2f, D, 1, (long)D * D, A, D, D, D, D, up(w.w2p)},
             {ws + w.w3f, D, 1, (long)Opad * D, A, O, D, (int)as_round_up(O, OUT_BN), D, up(w.w3p)},
             {ws + w.w2f, 1, D, (long)D * D, A, D, D, D, D, up(w.w2tp)},
             {ws + w.w3f, 1, D, (long)Opad * D, A, D, O, D, Opad, up(w.w3tp)},
+            {ws + w.w1f, 1, H, 0, 1, H, A * D, (int)as_round_up(H, 128), A * D, up(w.w1tp)},
         };
-        AS_STEP("head.planes", st, as_emit_planes(j, 5, st));
+        AS_STEP("head.planes", st, as_emit_planes(j, 6, st));
     }
     return 0;
 }
@@ -266,6 +277,8 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
         lo.bias = ws + w.b3f; lo.bias_batch = O;
         lo.out = out; lo.ldo = (long)A * O; lo.o_batch = O;
         lo.M = R; lo.N = O; lo.K = D; lo.batch = A;
+        lo.Bp = reinterpret_cast<const uint16_t*>(ws + w.w3p); lo.bp_rows = (int)as_round_up(O, OUT_BN);
+        lo.bp_batch = as_planes_batch_stride(lo.bp_rows, D); lo.bp_plane = A * lo.bp_batch;
         int n_part = 0;
         if (crit) {
             lo.tgt = crit->tgt; lo.tgt_T = crit->tgt_T; lo.lengths = crit->lengths; lo.T = crit->T; lo.scale = crit->scale;
@@ -338,9 +351,30 @@ int head_bwd_dx(const as_dims& d, const as_layout& L, const float* P, const floa
         AS_STEP("headb.dx2", st, gemm_nn(ws + w.dz2, AD, ws + w.w2f, D, ws + w.dz1, AD, R, D, D, st, A, D, (long)D * D, D));
         AS_STEP("headb.norm1", st, as_normalize_bwd(ws + w.dz1, ws + w.r1hat, ws + w.rstd1, nullptr, ws + w.dz1, rows * A, D, st, bits1));
     }
-    // N = H columns only (100 x 2 tiles of 64 x 64) under a 2816-long reduction: split K over the main-stream slab
-    AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st, 1, 0, 0, 0, ws + w.slab));
-    AS_STEP("headb.norm0", st, as_normalize_bwd(ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st));
+    // d(x_hat) = dz1 . W1' summed over the heads: N = H columns under an A * 256-long reduction.  Split arithmetic: 64 x 128
+    // tiles, the reduction cut into chunks whose partial sums the LayerNorm backward below adds (as_lin_plain_s6); else the
+    // general kernel (100 x 2 tiles of 64 x 64, split K over the main-stream slab)
+    int dx1_slabs = 0;
+    if (H <= 256 && H % 4 == 0) {
+        as_lin l{};
+        l.A = ws + w.dz1; l.lda = AD;
+        l.Bp = reinterpret_cast<const uint16_t*>(ws + w.w1tp); l.bp_rows = (int)as_round_up(H, 128);
+        l.bp_batch = as_planes_batch_stride(l.bp_rows, (int)AD); l.bp_plane = l.bp_batch;
+        l.C = ws + w.slab; l.ldc = H;
+        l.M = R; l.N = H; l.K = (int)AD; l.batch = 1;
+        const int want = (int)std::max<int64_t>(1, std::min<int64_t>(8, 512 / std::max(1, as_cdiv(R, 64))));
+        const int slabs = as_lin_plain_s6_slabs((int)AD, want);
+        if ((int64_t)slabs * R * H <= SLAB_FLOATS) {
+            AS_PROF("headb.dx1", st);
+            const int took1 = as_lin_plain_s6(&l, want, (long)R * H, st);
+            AS_REQUIRE(took1 >= 0, took1, "head dx1: launch failed");
+            if (took1) dx1_slabs = slabs;
+        }
+    }
+    if (!dx1_slabs)
+        AS_STEP("headb.dx1", st, gemm_nn(ws + w.dz1, AD, ws + w.w1f, H, ws + w.dxhat, H, R, H, (int)AD, st, 1, 0, 0, 0, ws + w.slab));
+    AS_STEP("headb.norm0", st, as_normalize_bwd(dx1_slabs ? ws + w.slab : ws + w.dxhat, ws + w.xhat, ws + w.rstd0, relu_src, dx, rows, H, st, nullptr,
+                                                 dx1_slabs ? dx1_slabs : 1, (long)R * H));
     return 0;
 }
 
@@ -649,6 +683,16 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, st));
         AS_TRY(as_count_bad_tokens(tokens, tok_stride, T, R, V, reinterpret_cast<int*>(ws + w.tokflag), st));
     }
+    const bool s6 = !d->simple && w.xp_bn && as_matrix_arith() == AS_ARITH_BF16X6;
+    if (s6) {
+        // GRU layer-1 input weights as bfloat16 planes: one small launch on the caller's stream (they depend on parameters the previous optimizer step on this stream has just written)
+        auto up = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
+        const int bn = w.xp_bn;
+        as_planes_job j[1] = {
+            {P + L.w_ih[1], 2L * H, 1, (long)bn * 2 * H, 6 * H / bn, bn, 2 * H, bn, 2 * H, up(w.wih1p)},
+        };
+        AS_STEP("gru.planes", st, as_emit_planes(j, 1, st));
+    }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
         if ((long)V * E <= 16384)   // the step's first kernel, on its critical path: a small dedicated kernel (rowops.hip)
@@ -678,11 +722,26 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
                 took = as_lin_try(&l, st);
                 AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
             }
+            if (!took && s6) {   // split arithmetic: 6H / bn column blocks of bn
+                const int bn = w.xp_bn;
+                as_lin l{};
+                l.A = l1_in; l.lda = 2 * H;
+                l.Bp = reinterpret_cast<const uint16_t*>(ws + w.wih1p); l.bp_rows = bn; l.bp_batch = as_planes_batch_stride(bn, 2 * H);
+                l.bp_plane = (6 * H / bn) * l.bp_batch;
+                l.C = ws + w.xp1; l.ldc = 6 * H; l.c_batch = bn;
+                l.bias = P + L.b_ih[1]; l.bias_batch = bn;
+                l.M = R; l.N = bn; l.K = 2 * H; l.batch = 6 * H / bn;
+                AS_PROF("gru.xproj1", st);
+                took = as_lin_plain_s6(&l, 1, 0, st);
+                AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
+            }
             if (!took)
                 AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
         }
         AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
                                 train ? ws + w.g1 : nullptr, st));
+        // (the trunk Linear and its input gradient stay on the general fp32-MFMA kernel: on the split-arithmetic kernel they
+        // were measured slower -- 15 vs 10 us, 14 vs 9 us -- 100-200 workgroups that each stream the whole weight from L2)
         AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
     } else if (pdrop > 0.f) {
         // SimpleArtSpeech in training mode (models.py:64,85): Dropout acts on the embedded frame, so every position has its
@@ -795,6 +854,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
             took = as_lin_try(&l, st);
             AS_REQUIRE(took >= 0, took, "grub.dx1: launch failed");
         }
+        // (split arithmetic measured slower here, 56 vs 52 us: 200 workgroups x 1.2 MB of weight planes each from L2)
         if (!took)
             AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
     }

@@ -56,6 +56,16 @@ struct as_lin {
     int tile_rows;   // 0 = the mixed tile list (64-row tiles that fill whole rounds, then 32-row tiles); 64 / 32 = that size only
 };
 int as_lin_try(const as_lin* a, hipStream_t st);
+// lin_f32.hip: epi 0 on the bf16 matrix instruction (a->Bp required; a->B unused): C = act(A . B^T + bias), N <= 256, K % 32 == 0.
+// ksplit > 1: the reduction is cut into that many chunks, chunk y writes its partial sums (no bias / activation allowed) to
+// C + y * c_split floats; the CONSUMER adds the slabs.  1 = launched, 0 = not a case (mode fp32, shapes), < 0 = error.
+int as_lin_plain_s6(const as_lin* a, int ksplit, long c_split, hipStream_t st);
+// the number of k-chunks (slabs) as_lin_plain_s6 really uses for a requested ksplit
+static inline int as_lin_plain_s6_slabs(int K, int ksplit) {
+    if (ksplit < 1) ksplit = 1;
+    const int kchunk = (int)as_round_up(as_cdiv(K, ksplit), 32);
+    return as_cdiv(K, kchunk);
+}
 
 // lin_f32.hip: the heads' output layer out[M][batch][N] = sigmoid(A[M][batch][K] . B[batch][>= 128 rows][K]^T + bias), N <= 128,
 // optionally with the masked Euclidean criterion fused (tgt != NULL): loss partials (one per workgroup, `partial`, at most
@@ -68,6 +78,7 @@ struct as_lin_out {
     int M, N, K, batch;
     const float* tgt; long tgt_T; const int* lengths; int T; float scale;
     float* dout; float* partial; long partial_capacity;
+    const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // optional: B as bfloat16 planes, bp_rows >= 128 (see as_lin.Bp)
 };
 int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st);
 // metrics.hip: *loss = scale * sum of the first n partials (fixed order)

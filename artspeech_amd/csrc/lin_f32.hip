@@ -38,6 +38,7 @@ struct LinK {
     const float* A; long lda, a_batch;
     const float* B; long ldb, b_batch;
     const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // lin_s6_kernel: B as three bfloat16 planes (as_lin.Bp)
+    int kchunk; long c_split;           // lin_s6_plain_kernel: blockIdx.y = k-chunk of kchunk, its partial result at C + y * c_split
     float* C; long ldc, c_batch;
     const float* bias; long bias_batch;
     int M, N, K, ka_valid, batch, act;
@@ -446,6 +447,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
 
+// Workgroups go to the eight XCDs round-robin by block index, and each XCD has its own 4 MB L2.  With tiles numbered head
+// by head, block b -> tile b puts every head's weights into every L2 (11 heads x 393 KB of planes do not fit one).  This map
+// gives XCD x a CONTIGUOUS range of the tile list instead (two or three heads): block b = x + 8 i -> tile start(x) + i.
+__device__ __forceinline__ int xcd_contiguous(int b, int total) {
+    const int q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 constexpr int S6_BK = 32;                 // k-tile of the A image (two MFMA k-steps)
 constexpr int S6_PLANE = 64 * S6_BK * 2;  // bytes of one plane of one k-tile: 64 rows x 32 bf16
 constexpr int S6_BUF = 3 * S6_PLANE;
@@ -580,12 +589,13 @@ __global__ __launch_bounds__(NT, 4) void lin_s6_kernel(LinK g) {
     static_assert(EPIT * 4 >= 2 * S6_BUF, "the epilogue's staging area holds both plane images");
     __shared__ __attribute__((aligned(16))) float smem[EPIT];
     int bz, m0, tm_eff;
-    if ((int)blockIdx.x < g.n_big) {
-        bz = blockIdx.x / g.big_per_batch;
-        m0 = (blockIdx.x - bz * g.big_per_batch) * 64;
+    const int tile = blockIdx.x;   // (an XCD-contiguous map of the tile list, xcd_contiguous(), was measured: 5-10 % slower)
+    if (tile < g.n_big) {
+        bz = tile / g.big_per_batch;
+        m0 = (tile - bz * g.big_per_batch) * 64;
         tm_eff = 2;
     } else {
-        const int j = blockIdx.x - g.n_big;
+        const int j = tile - g.n_big;
         bz = j / g.small_per_batch;
         m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
         tm_eff = 1;
@@ -628,6 +638,60 @@ __global__ __launch_bounds__(NT, 4) void lin_s6_kernel(LinK g) {
     }
 }
 
+// A plain Linear on the same main loop: C = act(A . B^T + bias), 64 (or 32) rows x 32 NW columns per workgroup (NW = 8:
+// N <= 256, NW = 4: N <= 128; four workgroups per CU at NW = 4), optionally split over K (gridDim.y chunks of kchunk, each
+// writing its partial sums -- no bias, no activation -- to its own slab C + y * c_split: the consumer adds them in a fixed order).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void lin_s6_plain_kernel(LinK g) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * S6_BUF];
+    int bz, m0, tm_eff;
+    const int tile = blockIdx.x;   // (an XCD-contiguous map of the tile list, xcd_contiguous(), was measured: 5-10 % slower)
+    if (tile < g.n_big) {
+        bz = tile / g.big_per_batch;
+        m0 = (tile - bz * g.big_per_batch) * 64;
+        tm_eff = 2;
+    } else {
+        const int j = tile - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        tm_eff = 1;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ks = blockIdx.y, k0 = ks * g.kchunk;
+    const int klen = min(g.kchunk, g.K - k0);
+    const int kav = max(0, min(klen, g.ka_valid - k0));
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const long bp_step = (long)g.bp_rows * 16;
+    const uint16_t* bp = g.Bp + (long)bz * g.bp_batch + (k0 / 16) * bp_step;
+    const unsigned b_lane = (unsigned)((wave * 32 + l31) * 16 + lh * 8) * 2u;   // bytes
+    const float* A = g.A + (long)bz * g.a_batch + (long)m0 * g.lda + k0;
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+    if (tm_eff == 2) s6_main_loop<NW, 2>(acc, sm, A, g.lda, g.M - m0, klen, kav, bp, b_lane, g.bp_plane, bp_step, tid, lane, late);
+    else s6_main_loop<NW, 1>(acc, sm, A, g.lda, g.M - m0, klen, kav, bp, b_lane, g.bp_plane, bp_step, tid, lane, late);
+    const int col = wave * 32 + l31;
+    if (col >= g.N) return;
+    const bool whole = gridDim.y == 1;
+    const float bj = (whole && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    float* c0 = g.C + (long)ks * g.c_split + (long)bz * g.c_batch + col;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (i < tm_eff && row < g.M) {
+                float v = acc[i][r] + bj;
+                if (whole && g.act == 1) v = as_relu(v);
+                else if (whole && g.act == 2) v = as_sigmoid(v);
+                c0[(long)row * g.ldc] = v;
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Output layer of the heads: out = sigmoid(x_hat . W3'^T + b3') (models.py:28-31, 145), N = 2 x n_samples <= 128 columns per
 // head, optionally with the training criterion fused into the epilogue (EuclideanDistance + padding mask + mean,
@@ -653,6 +717,7 @@ struct LinOutK {
     // fused criterion (tgt == nullptr: plain output layer)
     const float* tgt; long tgt_T; const int* lengths; int T; float scale;
     float* dout; float* partial;
+    const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // lin_out_s6_kernel: W3' as bfloat16 planes (as_lin_out.Bp)
 };
 
 __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
@@ -824,6 +889,142 @@ __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
     if (tid == 0) g.partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
+// The output layer on the bf16 matrix instruction (see lin_s6_kernel): 4 waves, wave w = columns 32 w .. 32 w + 31 of all 64
+// rows (two accumulators), A split once per workgroup into the plane image, W3' planes from L2 into registers.  32 KB of
+// LDS, <= 128 VGPRs: four workgroups per CU.  Epilogue as lin_out_kernel's, with 16 instead of 8 frames per wave.
+__global__ __launch_bounds__(256, 4) void lin_out_s6_kernel(LinOutK g) {
+    __shared__ __attribute__((aligned(16))) float smem[64 * ON];
+    static_assert(64 * ON * 4 >= 2 * S6_BUF, "the epilogue's tile holds both plane images");
+    int bz, m0, rows;
+    const int tile = blockIdx.x;   // (an XCD-contiguous map of the tile list, xcd_contiguous(), was measured: 5-10 % slower)
+    if (tile < g.n_big) {
+        bz = tile / g.big_per_batch;
+        m0 = (tile - bz * g.big_per_batch) * 64;
+        rows = 64;
+    } else {
+        const int j = tile - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        rows = 32;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const uint16_t* bp = g.Bp + (long)bz * g.bp_batch;
+    const unsigned b_lane = (unsigned)((wave * 32 + l31) * 16 + lh * 8) * 2u;   // bytes
+    unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+    const float* A = g.A + (long)bz * g.a_batch + (long)m0 * g.lda;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    if (rows == 64) s6_main_loop<4, 2>(acc, sm, A, g.lda, g.M - m0, g.K, g.K, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane, wave_u >= 2);
+    else s6_main_loop<4, 1>(acc, sm, A, g.lda, g.M - m0, g.K, g.K, bp, b_lane, g.bp_plane, (long)g.bp_rows * 16, tid, lane, wave_u >= 2);
+    // ---- epilogue.  D[row][col]: col = wave * 32 + l31, row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh
+    const int col = wave * 32 + l31;
+    const float bj = (g.bias && col < g.N) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    const int nblk = rows / 32;
+    if (g.tgt == nullptr) {
+        if (col < g.N) {
+            float* o0 = g.out + (long)bz * g.o_batch + col;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (i < nblk && row < g.M) o0[(long)row * g.ldo] = as_sigmoid(acc[i][r] + bj);
+                }
+        }
+        return;
+    }
+    // fused criterion: sigmoid outputs through LDS ([64][ON]; every plane-image read is behind the loop's last barrier)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (i < nblk) smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ON + col] = as_sigmoid(acc[i][r] + bj);
+    lds_barrier();
+    const int Np = g.N >> 1;                                    // points per contour
+    float part = 0.f;
+    if (Np <= 64) {
+        // one wave per frame at a time, lanes over the points, 8 frames per pass with ALL their target coordinates requested
+        // before the first store goes out (see lin_out_kernel)
+        const int nl = min(lane, Np - 1);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            float tx[8], ty[8];
+            bool in[8], valid[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = wave_u + 4 * (8 * pass + k);
+                const int frame = m0 + r;
+                in[k] = r < rows && frame < g.M;
+                const int fc = in[k] ? frame : m0;
+                const int b = fc / g.T, t = fc - b * g.T;
+                valid[k] = in[k] && t < g.lengths[b];
+                const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
+                tx[k] = tg[nl];
+                ty[k] = tg[Np + nl];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!in[k]) continue;                       // wave-uniform
+                const int r = wave_u + 4 * (8 * pass + k);
+                const long frame = m0 + r;
+                float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
+                float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
+                if (lane < Np) {
+                    const float ox = smem[r * ON + lane], oy = smem[r * ON + Np + lane];
+                    o[lane] = ox;
+                    o[Np + lane] = oy;
+                    float gx = 0.f, gy = 0.f;
+                    if (valid[k]) {
+                        const float dx = ox - tx[k], dy = oy - ty[k];
+                        const float d = sqrtf(dx * dx + dy * dy);
+                        part += d;
+                        const float gg = g.scale / d;                   // NaN at zero distance, as torch autograd
+                        gx = dx * gg * ox * (1.f - ox);                  // through the sigmoid (same product order as the unfused kernels)
+                        gy = dy * gg * oy * (1.f - oy);
+                    }
+                    dz[lane] = gx;
+                    dz[Np + lane] = gy;
+                }
+            }
+        }
+    } else
+    for (int r = wave_u; r < rows; r += 4) {
+        const int frame = m0 + r;
+        if (frame >= g.M) break;
+        const int b = frame / g.T, t = frame - b * g.T;
+        const bool valid = t < g.lengths[b];
+        float* o = g.out + (long)frame * g.ldo + (long)bz * g.o_batch;
+        float* dz = g.dout + (long)frame * g.ldo + (long)bz * g.o_batch;
+        const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
+        for (int n = lane; n < Np; n += 64) {
+            const float ox = smem[r * ON + n], oy = smem[r * ON + Np + n];
+            o[n] = ox;
+            o[Np + n] = oy;
+            float gx = 0.f, gy = 0.f;
+            if (valid) {
+                const float dx = ox - tg[n], dy = oy - tg[Np + n];
+                const float d = sqrtf(dx * dx + dy * dy);
+                part += d;
+                const float gg = g.scale / d;
+                gx = dx * gg * ox * (1.f - ox);
+                gy = dy * gg * oy * (1.f - oy);
+            }
+            dz[n] = gx;
+            dz[Np + n] = gy;
+        }
+    }
+    part = wave_sum(part);
+    __shared__ float red[4];
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    if (tid == 0) g.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);   // (tile order, like lin_out_kernel: same final sum order)
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Tile list.  Two workgroups per CU = 512 slots; a launch of T equal tiles takes ceil(T / 512) rounds, and the head
@@ -905,7 +1106,7 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     if (k.ka_valid % 4) return 0;
     // B as bfloat16 planes (as_emit_planes) and the split arithmetic on: the bf16-MFMA kernel; else the exact fp32 one
     if (a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= BN && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
-        a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0) {
+        a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0 && a->lda < (1L << 23)) {
         k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
     }
     if (a->epi == EPI_LNF) {
@@ -918,6 +1119,44 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
     }
     if (a->b_kc) return launch<true, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
     return launch<false, EPI_PLAIN>(k, st) == 0 ? 1 : -1;
+}
+
+// see gemm_internal.h
+int as_lin_plain_s6(const as_lin* a, int ksplit, long c_split, hipStream_t st) {
+    if (as_matrix_arith() != AS_ARITH_BF16X6 || !a->Bp) return 0;
+    if (a->epi != EPI_PLAIN || a->K % S6_BK || a->K < S6_BK || a->N > BN || a->N < 1 || a->M < 1 || a->batch < 1 || !a->C) return 0;
+    if (!aligned16(a->A) || a->lda % 4 || a->a_batch % 4 || a->lda >= (1L << 23)) return 0;
+    if ((reinterpret_cast<uintptr_t>(a->Bp) & 15) || a->bp_plane % 8 || a->bp_batch % 8) return 0;
+    const int nw = a->N <= 128 ? 4 : 8;
+    if (a->bp_rows < nw * 32) return 0;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 1 && (a->bias || a->act)) return 0;
+    LinK k{};
+    k.A = a->A; k.lda = a->lda; k.a_batch = a->a_batch;
+    k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
+    k.C = a->C; k.ldc = a->ldc; k.c_batch = a->c_batch;
+    k.bias = a->bias; k.bias_batch = a->bias_batch;
+    k.M = a->M; k.N = a->N; k.K = a->K; k.ka_valid = a->ka_valid > 0 ? a->ka_valid : a->K; k.batch = a->batch; k.act = a->act;
+    if (k.ka_valid % 4) return 0;
+    k.kchunk = (int)as_round_up(as_cdiv(a->K, ksplit), S6_BK);
+    ksplit = as_cdiv(a->K, k.kchunk);
+    k.c_split = c_split;
+    // tiles: 64 rows unless that leaves CUs idle (fewer workgroups than 1.5 x 256)
+    int tile = a->tile_rows;
+    if (tile != 32 && tile != 64) tile = (long)as_cdiv(a->M, 64) * a->batch * ksplit >= 384 ? 64 : 32;
+    const int x = tile == 64 ? a->M / 64 : 0;
+    const int rest = a->M - x * 64;
+    k.big_per_batch = x > 0 ? x : 1;
+    k.big_per_batch_rows = x * 64;
+    k.n_big = x * a->batch;
+    k.small_per_batch = as_cdiv(rest, 32);
+    const long total = (long)k.n_big + (long)k.small_per_batch * a->batch;
+    if (k.small_per_batch == 0) k.small_per_batch = 1;
+    if (total > (1L << 30) || ksplit > 65535) return 0;
+    if (nw == 4) hipLaunchKernelGGL((lin_s6_plain_kernel<4>), dim3((unsigned)total, ksplit), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((lin_s6_plain_kernel<8>), dim3((unsigned)total, ksplit), dim3(512), 0, st, k);
+    AS_LAUNCH_CHECK("as_lin_plain_s6");
+    return 1;
 }
 
 // Output layer of the heads, optionally with the masked Euclidean criterion and its gradient fused in (see lin_out_kernel).
@@ -952,6 +1191,14 @@ int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st) {
     const long total = (long)k.n_big + (long)k.small_per_batch * k.batch;
     if (k.small_per_batch == 0) k.small_per_batch = 1;
     if (k.tgt && total > a->partial_capacity) return 0;
+    if (a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= ON && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
+        a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0 && a->lda < (1L << 23)) {
+        k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
+        hipLaunchKernelGGL(lin_out_s6_kernel, dim3((unsigned)total), dim3(256), 0, st, k);
+        AS_LAUNCH_CHECK("as_lin_out_s6");
+        if (n_partials) *n_partials = (int)total;
+        return 1;
+    }
     hipLaunchKernelGGL(lin_out_kernel, dim3((unsigned)total), dim3(NT), 0, st, k);
     AS_LAUNCH_CHECK("as_lin_out");
     if (n_partials) *n_partials = (int)total;

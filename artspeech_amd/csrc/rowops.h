@@ -6,7 +6,8 @@
 // as_normalize_bwd can take as relu_bits instead of re-reading the activation itself (relu_src)
 int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D, hipStream_t st, unsigned long long* pos_bits = nullptr);
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
-                     int D, hipStream_t st, const unsigned long long* relu_bits = nullptr);
+                     int D, hipStream_t st, const unsigned long long* relu_bits = nullptr, int n_slab = 1, long slab_stride = 0);
+// (n_slab > 1: dy is the sum of n_slab partial results slab_stride floats apart, added in slab order)
 // Rpad (>= R, 0 = R): rows per head in Wf; the extra rows are written as zeros
 int as_fold(const float* W, const float* gamma, const float* beta, const float* b, float* Wf, float* bf, int heads, int R,
             int K, hipStream_t st, int Rpad = 0);

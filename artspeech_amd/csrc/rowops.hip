@@ -70,7 +70,8 @@ template <int MW, bool MASKED, bool WHOLE>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ relu_src, float* dx,
-                                                            long rows, int D, const unsigned long long* __restrict__ relu_bits) {
+                                                            long rows, int D, const unsigned long long* __restrict__ relu_bits,
+                                                            int n_slab, long slab_stride) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -84,6 +85,15 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* dy, con
         g[c] = dyr[ic];
         h[c] = xr[ic];
         if (MASKED) m[c] = 1.f;
+    }
+    // dy = the sum of n_slab partial results (a GEMM split over K, as_lin_plain_s6), added in slab order
+    for (int sl = 1; sl < n_slab; ++sl) {
+#pragma unroll
+        for (int c = 0; c < MW; ++c) {
+            const int i = lane + 64 * c;
+            const int ic = WHOLE ? lane + (64 * c < D ? 64 * c : 0) : (i < D ? i : D - 1);
+            g[c] += dyr[sl * slab_stride + ic];
+        }
     }
     if (MASKED && relu_src) {  // (one uniform branch around the whole batch, not one per element)
         const float* rr = relu_src + row * D;
@@ -161,47 +171,40 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ W, 
 struct PlanesJobs { as_planes_job j[8]; long first[9]; };
 
 __global__ __launch_bounds__(256) void emit_planes_kernel(PlanesJobs jobs, int n_jobs) {
+    // one thread per PAIR of consecutive k (one packed word of each plane): enough threads to hide the loads' latency -- a
+    // thread per 16-deep row segment made the launch a chain of 12 k threads with 16 strided loads each (21 us for 0.4 M elements)
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= jobs.first[n_jobs]) return;
     int q = 0;
     while (q + 1 < n_jobs && gid >= jobs.first[q + 1]) ++q;
     const as_planes_job& J = jobs.j[q];
     long r = gid - jobs.first[q];
+    const int e = (int)(r & 7);
+    r >>= 3;
     const int n = (int)(r % J.rows_pad);
     r /= J.rows_pad;
     const int nks = J.Kpad / 16;
     const int ks = (int)(r % nks), b = (int)(r / nks);
-    unsigned hi[8], mid[8], lo[8];
     const float* src = J.B + (long)b * J.batch_stride + (long)n * J.n_stride;
+    const int k = ks * 16 + 2 * e;
+    float v[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = ks * 16 + 2 * e;
-        float v[2];
+    for (int h = 0; h < 2; ++h) v[h] = (n < J.N && k + h < J.K) ? src[(long)(k + h) * J.k_stride] : 0.f;
+    unsigned short p[3][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) v[h] = (n < J.N && k + h < J.K) ? src[(long)(k + h) * J.k_stride] : 0.f;
-        unsigned short p[3][2];
+    for (int h = 0; h < 2; ++h) {
+        float x = v[h];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float x = v[h];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const __bf16 t = (__bf16)x;                       // round to nearest even
-                p[pl][h] = __builtin_bit_cast(unsigned short, t);
-                x -= (float)t;                                    // exact
-            }
+        for (int pl = 0; pl < 3; ++pl) {
+            const __bf16 t = (__bf16)x;                       // round to nearest even
+            p[pl][h] = __builtin_bit_cast(unsigned short, t);
+            x -= (float)t;                                    // exact
         }
-        hi[e] = p[0][0] | ((unsigned)p[0][1] << 16);
-        mid[e] = p[1][0] | ((unsigned)p[1][1] << 16);
-        lo[e] = p[2][0] | ((unsigned)p[2][1] << 16);
     }
     const long bstride = (long)nks * J.rows_pad * 16, pstride = (long)J.batch * bstride;
-    uint16_t* o = J.out + (long)b * bstride + ((long)ks * J.rows_pad + n) * 16;
-    uint4* o0 = reinterpret_cast<uint4*>(o);
-    uint4* o1 = reinterpret_cast<uint4*>(o + pstride);
-    uint4* o2 = reinterpret_cast<uint4*>(o + 2 * pstride);
-    o0[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);   o0[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-    o1[0] = make_uint4(mid[0], mid[1], mid[2], mid[3]); o1[1] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
-    o2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);   o2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    unsigned* o = reinterpret_cast<unsigned*>(J.out + (long)b * bstride + ((long)ks * J.rows_pad + n) * 16) + e;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) o[pl * (pstride / 2)] = p[pl][0] | ((unsigned)p[pl][1] << 16);
 }
 
 // ---- unfold: dW[n][k] = dWf[n][k] * gamma[k] + dbf[n] * beta[k] ; dgamma[k] = sum_n dWf[n][k] W[n][k] ;
@@ -900,9 +903,10 @@ int as_normalize_fwd(const float* x, float* xhat, float* rstd, long rows, int D,
     return 0;
 }
 int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, const float* relu_src, float* dx, long rows,
-                     int D, hipStream_t st, const unsigned long long* relu_bits) {
+                     int D, hipStream_t st, const unsigned long long* relu_bits, int n_slab, long slab_stride) {
     AS_REQUIRE(D > 0 && D <= 64 * MAXCW, AS_ERR_UNSUPPORTED, "normalize: row length %d > %d", D, 64 * MAXCW);
-    if (!relu_src && !relu_bits && wide_ok(D, dy, xhat, dx)) {
+    if (n_slab < 1) n_slab = 1;
+    if (!relu_src && !relu_bits && n_slab == 1 && wide_ok(D, dy, xhat, dx)) {
         hipLaunchKernelGGL(normalize_bwd_wide_kernel, dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, dx, rows, D);
         AS_LAUNCH_CHECK("normalize_bwd");
         return 0;
@@ -911,13 +915,13 @@ int as_normalize_bwd(const float* dy, const float* xhat, const float* rstd, cons
     do {                                                                                                                               \
         if (relu_src || relu_bits)                                                                                                     \
             hipLaunchKernelGGL((normalize_bwd_kernel<MW, true, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
-                               dx, rows, D, relu_bits);                                                                                \
+                               dx, rows, D, relu_bits, n_slab, slab_stride);                                                           \
         else if (D % 64 == 0)                                                                                                          \
             hipLaunchKernelGGL((normalize_bwd_kernel<MW, false, true>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
-                               dx, rows, D, relu_bits);                                                                                \
+                               dx, rows, D, relu_bits, n_slab, slab_stride);                                                           \
         else                                                                                                                           \
             hipLaunchKernelGGL((normalize_bwd_kernel<MW, false, false>), dim3(as_cdiv(rows, 4)), dim3(256), 0, st, dy, xhat, rstd, relu_src, \
-                               dx, rows, D, relu_bits);                                                                                \
+                               dx, rows, D, relu_bits, n_slab, slab_stride);                                                           \
     } while (0)
     if (D <= 128) AS_NORM_BWD(2);
     else if (D <= 256) AS_NORM_BWD(4);
@@ -945,7 +949,7 @@ int as_emit_planes(const as_planes_job* jobs, int n, hipStream_t st) {
                    (reinterpret_cast<uintptr_t>(J.out) & 15) == 0, AS_ERR_BAD_ARG, "as_emit_planes: bad job %d", i);
         pj.j[i] = J;
         pj.first[i] = total;
-        total += (long)J.batch * (J.Kpad / 16) * J.rows_pad;
+        total += (long)J.batch * (J.Kpad / 16) * J.rows_pad * 8;
     }
     pj.first[n] = total;
     hipLaunchKernelGGL(emit_planes_kernel, dim3(as_cdiv(total, 256)), dim3(256), 0, st, pj, n);

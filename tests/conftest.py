@@ -46,7 +46,10 @@ def assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=1e-5, atol_abs=0.0):
     return rel_of_max
 
 
-def oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, n_art, tau=5e-6, max_flips=8):
+FLIPS = {}   # test label -> [(where, index, z)]: every ReLU decision a parity test took from the device (written at session end)
+
+
+def oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, n_art, tau=5e-6, max_flips=8, label=None):
     """The fp64 oracle and an fp32 implementation can disagree about `z > 0` where the oracle's pre-activation z lies within
     rounding of zero; one such element changes the gradients of its head by about one frame's term and everything upstream
     with it (stock PyTorch fp32 against fp64 shows it in 9 of 40 seeded draws of a 450-frame batch: DESIGN section 2).  This
@@ -88,6 +91,8 @@ def oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, n_art, 
             return g["linear.1.weight"], g["linear.4.weight"]
         greedy([head_caches[a][3], head_caches[a][6]], [f"predictors.{a}.linear.1.weight", f"predictors.{a}.linear.4.weight"], grads, f"head {a}")
     greedy([zlin], ["linear.0.weight"], lambda: (O.artspeech_bwd(o_dout, cache, n_art)["linear.0.weight"],), "trunk")
+    if label is not None:
+        FLIPS[label] = [(w, list(i), float(z)) for w, i, z in flips]
     return O.artspeech_bwd(o_dout, cache, n_art), flips
 
 
@@ -100,6 +105,10 @@ def pytest_sessionfinish(session, exitstatus):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_worst_errors.json"), "w") as f:
             json.dump({k: float(f"{v:.3e}") for k, v in sorted(WORST.items())}, f, indent=1)
+        # the ReLU decisions the gradient checks took from the device instead of the fp64 oracle: where, element, oracle input z
+        with open(os.path.join(out, "parity_relu_flips.json"), "w") as f:
+            json.dump({"tests": FLIPS, "count": sum(len(v) for v in FLIPS.values()),
+                       "max_abs_z": max([abs(z) for v in FLIPS.values() for _, _, z in v], default=0.0)}, f, indent=1)
     except OSError:
         pass
 

@@ -724,9 +724,13 @@ def test_artspeech_vs_oracle_more_than_1024_frames(dev, V):
     assert_close(out.detach().cpu().numpy(), o_out, what="contours")
     o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
     assert abs(loss.item() - o_loss) < 1e-6
-    og = O.artspeech_bwd(o_dout, cache, A)
-    for k, v in model.named_grad_views().items():
-        assert_grad_close(v.cpu().numpy(), og[k], f"1280 frames, V={V}, vs oracle: {k}")
+    # (ReLU decisions within rounding of zero are taken from the device, at most two of the 0.5 M: conftest.py; with the
+    # split matrix arithmetic the V = 100 draw has one, oracle input 1e-7-sized, in head 1 -- recorded in parity_relu_flips.json)
+    got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
+    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A, label=f"1280 frames, V={V}")
+    assert len(flips) <= 2 and all(abs(z) < 5e-6 for _, _, z in flips), flips
+    for k, v in got.items():
+        assert_grad_close(v, og[k], f"1280 frames, V={V}, vs oracle (ReLU decisions taken from the device: {flips}): {k}")
 
 
 @pytest.mark.parametrize("H", [48, 256, 36])
@@ -812,7 +816,7 @@ def test_artspeech_random_configurations_vs_oracle(dev, seed):
     # with the oracle's backward AT THE DEVICE'S CONTOURS: same criterion formula, same point of evaluation.
     _, o_dout = O.masked_euclid_loss(out.detach().cpu().numpy().astype(np.float64), tgt, lengths)
     got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
-    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A)
+    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A, label=str(c))
     assert len(flips) <= 4 and all(abs(z) < 5e-6 for _, _, z in flips), flips
     for k, v in got.items():
         assert_grad_close(v, og[k], f"{c} (ReLU decisions taken from the device: {flips}): {k}")
@@ -1204,8 +1208,12 @@ def test_full_size_every_gradient_vs_oracle(dev):
     # (criterion gradient evaluated at the device's contours: see test_artspeech_random_configurations_vs_oracle)
     _, o_dout = O.masked_euclid_loss(out.detach().cpu().numpy().astype(np.float64), tgt, lengths)
     got = {k: v.cpu().numpy() for k, v in model.named_grad_views().items()}
-    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A)
-    assert len(flips) <= 8 and all(abs(z) < 5e-6 for _, _, z in flips), flips
+    # 36 million ReLU inputs: about 17 lie within 6e-7 of zero (a few fp32 roundings of an O(1) pre-activation) and any fp32
+    # arithmetic decides about half of those differently from fp64 -- 5 with the fp32 matrix instruction, 9-12 with the split
+    # one (different, not larger, rounding: test_split_matrix_arithmetic_error_vs_fp64).  Each is recorded with its oracle
+    # input in gpurun_out/parity_relu_flips.json; the bound on |z| is what makes a flip legitimate, not the count.
+    og, flips = oracle_gradients_with_the_devices_relu_decisions(got, o_dout, cache, A, max_flips=16, label="full size B=32 T=200")
+    assert len(flips) <= 16 and all(abs(z) < 2e-6 for _, _, z in flips), flips
     bad = []
     for k, v in got.items():
         try:
