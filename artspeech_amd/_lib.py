@@ -73,6 +73,8 @@ PROTOTYPES = {
     "as_gru_bidir_fwd": (_I32, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gru_bidir_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "as_gemm_f32": (_I32, [C.POINTER(Gemm), _P]),
+    "as_linear_planes_floats": (_I64, [_I32, _I32]),
+    "as_linear_fwd": (_I32, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P]),
     "as_layernorm_fwd_blockres": (_I32, [_P, _P, _P, _P, _I32, _I64, _I32, _I32, _P]),
     "as_head_workspace_floats": (_I64, [_DIMS, _I64]),
     "as_head_fwd": (_I32, [_DIMS, _LAY, _P, _P, _I64, _P, _P, _I32, _P]),

@@ -1204,3 +1204,46 @@ int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st) {
     if (n_partials) *n_partials = (int)total;
     return 1;
 }
+
+// ---- include/artspeech_hip.h: as_linear_fwd
+namespace {
+// column blocks of the split-arithmetic plain kernel for an N-column Linear: block width (rows of the plane image) and count
+inline bool linear_blocks(int N, int* bn, int* nb) {
+    if (N <= 256) { *bn = N <= 128 ? 128 : 256; *nb = 1; return true; }
+    if (N % 256 == 0) { *bn = 256; *nb = N / 256; return true; }
+    return false;
+}
+}  // namespace
+
+extern "C" int64_t as_linear_planes_floats(int32_t N, int32_t K) {
+    int bn, nb;
+    if (N < 1 || K < 1 || !linear_blocks(N, &bn, &nb)) return 0;
+    return as_round_up(as_planes_floats(nb, bn, (int)as_round_up(K, 32)), 64);
+}
+
+extern "C" int as_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                             int32_t M, int32_t N, int32_t K, int32_t act, float* planes_ws, void* stream) {
+    AS_REQUIRE(A && W && out && M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldo >= N && act >= 0 && act <= 2, AS_ERR_BAD_ARG,
+               "as_linear_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int bn, nb;
+    if (as_matrix_arith() == AS_ARITH_BF16X6 && planes_ws && K % S6_BK == 0 && lda % 4 == 0 && linear_blocks(N, &bn, &nb) &&
+        (reinterpret_cast<uintptr_t>(planes_ws) & 15) == 0) {
+        const int rows_last = N - (nb - 1) * bn;   // (nb > 1: whole blocks)
+        as_planes_job j{W, ldw, 1, (long)bn * ldw, nb, nb > 1 ? bn : rows_last, K, bn, K, reinterpret_cast<uint16_t*>(planes_ws)};
+        AS_TRY(as_emit_planes(&j, 1, st));
+        as_lin l{};
+        l.A = A; l.lda = lda;
+        l.Bp = reinterpret_cast<const uint16_t*>(planes_ws); l.bp_rows = bn; l.bp_batch = as_planes_batch_stride(bn, K); l.bp_plane = nb * l.bp_batch;
+        l.C = out; l.ldc = ldo; l.c_batch = bn;
+        l.bias = bias; l.bias_batch = bn; l.act = act;
+        l.M = M; l.N = nb > 1 ? bn : N; l.K = K; l.batch = nb;
+        const int took = as_lin_plain_s6(&l, 1, 0, st);
+        AS_REQUIRE(took >= 0, took, "as_linear_fwd: launch failed");
+        if (took) return 0;
+    }
+    as_gemm g{};
+    g.A = A; g.B = W; g.C = out; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.a_i = lda; g.a_k = 1; g.b_j = ldw; g.b_k = 1; g.ldc = ldo; g.batch = 1; g.act = act;
+    return as_gemm_f32(&g, st);
+}

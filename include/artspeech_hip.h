@@ -263,6 +263,16 @@ typedef struct as_gemm {
 } as_gemm;
 int as_gemm_f32(const as_gemm* g, void* stream);
 
+/* nn.Linear forward, out[M][N] = act(A[M][K] . W[N][K]^T + bias) (act: 0 none, 1 ReLU, 2 sigmoid; the Linear layers of
+ * encoder_decoder/models.py:12-16, 113-116 and transformer/models.py:47-60), in the library's current matrix arithmetic
+ * (as_set_matrix_arith): mode 1 emits W as three bfloat16 planes into `planes_ws` (>= as_linear_planes_floats(N, K) floats of
+ * scratch, 16-byte aligned) and multiplies on v_mfma_f32_32x32x16_bf16 where the shape allows (K % 32 == 0; N <= 256 or
+ * N % 256 == 0; lda % 4 == 0); everything else -- and mode 0 -- runs as_gemm_f32.  tests/ hold both modes' error against an fp64
+ * product of the same operands. */
+int64_t as_linear_planes_floats(int32_t N, int32_t K);
+int as_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                  int32_t M, int32_t N, int32_t K, int32_t act, float* planes_ws, void* stream);
+
 /* ArticulatorPredictor x A + stack + sigmoid (encoder_decoder/models.py:7-33, 141-145) on rows of
  * `x` [rows][in]: out [rows][A][2][N].  Parameters are read from the flat buffer through `lay`.
  * ws: as_head_workspace_floats(). */

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from conftest import assert_grad_close, load_golden, oracle_gradients_with_the_devices_relu_decisions, split_wg
+from artspeech_amd import _lib
 from oracle import artspeech_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -135,6 +136,84 @@ def test_gemm_split_precision(dev, M, N, K):
     bt = np.ascontiguousarray(b.T)
     c = run_gemm(dev, T_(a, dev), T_(bt, dev), M, N, K, K, 1, 1, N, precision=1)
     assert_close(c.cpu().numpy().reshape(M, N), a.astype(np.float64) @ bt, rtol=2e-5, atol=2e-5 * np.sqrt(K), what="nn exact")
+
+
+@pytest.fixture
+def matrix_arith():
+    """tests that switch the library's matrix arithmetic restore the default (1 = split) afterwards"""
+    L = _lib.lib()
+    keep = L.as_get_matrix_arith()
+    yield L.as_set_matrix_arith
+    L.as_set_matrix_arith(keep)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(6400, 256, 256, 0), (6400, 256, 128, 1), (6400, 768, 256, 0), (6400, 128, 512, 0), (6400, 100, 256, 2),
+                                        (1000, 256, 2816, 0), (37, 130, 64, 1)])
+def test_split_matrix_arithmetic_error_vs_fp64(dev, matrix_arith, M, N, K, act):
+    """as_set_matrix_arith(1): every Linear shape the path ships on the bfloat16 matrix instruction (three planes per operand, six
+    plane products, fp32 accumulation; lin_s6_plain_kernel) against an fp64 product of the SAME fp32 operands: its maximum and
+    rms error must not exceed those of the exact-fp32 matrix instruction (mode 0) on the same operands -- `dtype: f32` of the
+    bench line is only honest with this held."""
+    L = _lib.lib()
+    rng = np.random.RandomState(M + N + K)
+    a = rng.randn(M, K).astype(np.float32)                              # normalised activations
+    w = ((rng.rand(N, K) * 2 - 1) / np.sqrt(K)).astype(np.float32)      # nn.Linear's default initialisation
+    bias = ((rng.rand(N) * 2 - 1) / np.sqrt(K)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    ref = np.maximum(ref, 0) if act == 1 else (1 / (1 + np.exp(-ref)) if act == 2 else ref)
+    da, dw, db = T_(a, dev), T_(w, dev), T_(bias, dev)
+    pw = torch.empty(max(64, L.as_linear_planes_floats(N, K)), device=dev)
+    err = {}
+    for mode in (0, 1):
+        matrix_arith(mode)
+        out = torch.full((M, N), float("nan"), device=dev)
+        _lib.check(L.as_linear_fwd(_lib.ptr(da), K, _lib.ptr(dw), K, _lib.ptr(db), _lib.ptr(out), N, M, N, K, act, _lib.ptr(pw), _lib.stream_ptr()))
+        e = out.cpu().numpy().astype(np.float64) - ref
+        err[mode] = (np.abs(e).max(), np.sqrt((e ** 2).mean()))
+    scale = np.abs(ref).max()
+    assert err[1][0] <= 1.05 * err[0][0] + 1e-7 * scale and err[1][1] <= 1.05 * err[0][1], (err, scale)
+    assert err[1][0] <= 2e-6 * scale * max(1.0, np.sqrt(K / 256)), (err, scale)   # (fp32 accumulation over K: grows like sqrt(K))
+
+
+def test_split_matrix_arithmetic_heads_error_vs_fp64(dev, matrix_arith):
+    """The fused head layers (Linear + ReLU + LayerNorm, lin_s6_kernel; output layer, lin_out_s6_kernel) in both arithmetics
+    against the fp64 oracle of ArticulatorPredictor (encoder_decoder/models.py:7-33) at 6400 frames x 11 heads: the split
+    arithmetic's contour error is not larger than the fp32 matrix instruction's, and both are far inside the 1e-4 contract."""
+    L = _lib.lib()
+    rows, A, H, N = 6400, 11, 128, 50
+    dims = _lib.Dims(45, A, 64, H, N, 0)
+    lay = _lib.layout(dims)
+    rng = np.random.RandomState(0)
+    x = np.maximum(rng.randn(rows, H), 0).astype(np.float32)
+    P = np.zeros(lay.total, np.float32)
+    ref = np.empty((rows, A, 2, N))
+    for a_ in range(A):
+        u = lambda *shape, fan: ((rng.rand(*shape) * 2 - 1) / np.sqrt(fan)).astype(np.float32)   # noqa: E731  nn.Linear's default
+        p = {"linear.0.weight": (1 + 0.1 * rng.randn(H)).astype(np.float32), "linear.0.bias": (0.1 * rng.randn(H)).astype(np.float32),
+             "linear.1.weight": u(256, H, fan=H), "linear.1.bias": u(256, fan=H),
+             "linear.3.weight": (1 + 0.1 * rng.randn(256)).astype(np.float32), "linear.3.bias": (0.1 * rng.randn(256)).astype(np.float32),
+             "linear.4.weight": u(256, 256, fan=256), "linear.4.bias": u(256, fan=256),
+             "linear.6.weight": (1 + 0.1 * rng.randn(256)).astype(np.float32), "linear.6.bias": (0.1 * rng.randn(256)).astype(np.float32),
+             "x_coords.weight": u(N, 256, fan=256), "x_coords.bias": u(N, fan=256), "y_coords.weight": u(N, 256, fan=256), "y_coords.bias": u(N, fan=256)}
+        pre, _ = O.predictor_fwd(x.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+        ref[:, a_] = 1 / (1 + np.exp(-pre))
+        for name, off, n in (("linear.0.weight", lay.ln1_g, H), ("linear.0.bias", lay.ln1_b, H), ("linear.1.weight", lay.w1, 256 * H),
+                             ("linear.1.bias", lay.b1, 256), ("linear.3.weight", lay.ln2_g, 256), ("linear.3.bias", lay.ln2_b, 256),
+                             ("linear.4.weight", lay.w2, 256 * 256), ("linear.4.bias", lay.b2, 256), ("linear.6.weight", lay.ln3_g, 256),
+                             ("linear.6.bias", lay.ln3_b, 256)):
+            P[off + a_ * n: off + (a_ + 1) * n] = p[name].reshape(-1)
+        P[lay.w3 + a_ * 2 * N * 256: lay.w3 + (a_ + 1) * 2 * N * 256] = np.concatenate([p["x_coords.weight"], p["y_coords.weight"]]).reshape(-1)
+        P[lay.b3 + a_ * 2 * N: lay.b3 + (a_ + 1) * 2 * N] = np.concatenate([p["x_coords.bias"], p["y_coords.bias"]])
+    Pd, xd = T_(P, dev), T_(x, dev)
+    ws = torch.empty(L.as_head_workspace_floats(C.byref(dims), rows), device=dev)
+    err = {}
+    for mode in (0, 1):
+        matrix_arith(mode)
+        out = torch.empty(rows, A, 2, N, device=dev)
+        _lib.check(L.as_head_fwd(C.byref(dims), C.byref(lay), _lib.ptr(Pd), _lib.ptr(xd), rows, _lib.ptr(out), _lib.ptr(ws), 0, _lib.stream_ptr()))
+        e = out.cpu().numpy().astype(np.float64) - ref
+        err[mode] = (np.abs(e).max(), np.sqrt((e ** 2).mean()))
+    assert err[1][1] <= 1.1 * err[0][1] and err[1][0] <= 1.5 * err[0][0] and err[1][0] < 2e-6, err
 
 
 def test_gemm_batched_strided_and_shift(dev):
