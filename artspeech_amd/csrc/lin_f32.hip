@@ -28,6 +28,8 @@
 #include "gemm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -100,6 +102,138 @@ __device__ __forceinline__ void lds_barrier() {  // LDS hazards only: unlike __s
     __builtin_amdgcn_s_barrier();
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row: four DPP steps, no
+// cross-row traffic, no v_readlane.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// ---- the LayerNorm epilogues.  The accumulators of a block of 32 rows (per group of 8 column waves) go to LDS, then every
+// wave normalises FOUR rows at a time: lane = (row rr = lane >> 4, slot jj = lane & 15) holds the 16 features
+// 64 c + 4 jj + e (c, e < 4) of its row -- four ds_read_b128 that are conflict-free (the 16 lanes one LDS cycle serves read
+// 256 consecutive bytes of two rows), row sums by four DPP steps inside the 16-lane row, stores as four
+// global_store_dwordx4 of 256 consecutive bytes per row.  (Before: one wave per row, 64 lanes x 4 features, two 64-lane sums
+// with v_readlane each and an IEEE 1 / sqrt per row, the four rows of a wave one after the other: 12 k cycles per 64-row
+// tile, as long as the split-arithmetic main loop.)
+//   NWC  column waves per row block (8).  Waves of row group wm = wave / NWC own tile rows wm * 64 + i * 32 + ...; the
+//        staging area holds one 32-row block per row group: [NG * 32][BN] floats, NG = number of row groups (1 | 2).
+//   EPI_LNF: x = relu(acc + bias); C = (x - mean) * rstd; rstd; bits (x > 0, one 32-bit piece per (row, column wave), taken
+//            from the accumulators by ballot before they leave for LDS).
+//   EPI_LNB: C = relu'(bits_in) * rstd_in * (acc - mean(acc) - xhat * mean(acc * xhat)).
+template <int TM, int EPI, int NWC>
+__device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], float* smem, int bz, int m0, int tm_eff, int n_groups_m1, int wave,
+                                            int lane, float bj) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wn = wave_u % NWC, wm = wave_u / NWC;       // column wave, row group
+    const int col = wn * 32 + l31;
+    const int rr = lane >> 4, jj = lane & 15;
+    constexpr float inv_d = 1.0f / BN;
+    // staged row of this lane in the normalisation phase: 4 * wave + rr of the NG * 32 staged rows; its tile row
+    const int srow = 4 * wave_u + rr;
+    const int trow_base = (srow >> 5) * 64 + (srow & 31);      // + i * 32
+    // backward: everything this wave reads from global memory is requested up front (vector memory operations retire in
+    // order: a load issued behind the first block's stores would wait for them)
+    f32x4 h[TM][4];
+    float rs_in[TM];
+    u32x4 mw[TM][2];
+    if (EPI == EPI_LNB) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long row = min((long)m0 + trow_base + i * 32, (long)g.M - 1);
+            const float* xr = g.xhat + (long)bz * g.x_batch + row * g.ldx + 4 * jj;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h[i][c] = *reinterpret_cast<const f32x4*>(xr + 64 * c);
+            rs_in[i] = g.rstd_in[row * g.batch + bz];
+            const u32x4* mp = reinterpret_cast<const u32x4*>(g.bits_in + (row * g.batch + bz) * 4);
+            mw[i][0] = mp[0];
+            mw[i][1] = mp[1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i >= tm_eff) break;
+        if (i > 0) lds_barrier();    // the previous block's rows are all read
+        float* st = smem + wm * 32 * BN;
+        if (EPI == EPI_LNF) {
+            unsigned mine = 0;        // lane L < 32: the mask piece (columns 32 wn .. 32 wn + 31) of block row L
+            // (v_writelane_b32 with the lane as an immediate: one instruction per piece -- a compare + select per piece would be
+            // four, and two scalar operands violate the constant-bus limit -- hence a macro over the literal register index)
+#define AS_LN_STAGE(r)                                                                                                        \
+            {                                                                                                                 \
+                const float v = as_relu(acc[i][r] + bj);                                                                      \
+                const unsigned long long b = __ballot(v > 0.f);                                                               \
+                /* gfx950: a scalar register written by a vector compare needs two wait states before a vector instruction */  \
+                /* reads it; hipcc's hazard pass does not look into inline assembly (seen: a stale mask piece, rarely)   */  \
+                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mine) : "s"((unsigned)b), "i"(((r) & 3) + 8 * ((r) >> 2))); \
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine) : "s"((unsigned)(b >> 32)), "i"(((r) & 3) + 8 * ((r) >> 2) + 4)); \
+                st[(((r) & 3) + 8 * ((r) >> 2) + 4 * lh) * BN + col] = v;                                                     \
+            }
+            AS_LN_STAGE(0) AS_LN_STAGE(1) AS_LN_STAGE(2) AS_LN_STAGE(3) AS_LN_STAGE(4) AS_LN_STAGE(5) AS_LN_STAGE(6) AS_LN_STAGE(7)
+            AS_LN_STAGE(8) AS_LN_STAGE(9) AS_LN_STAGE(10) AS_LN_STAGE(11) AS_LN_STAGE(12) AS_LN_STAGE(13) AS_LN_STAGE(14) AS_LN_STAGE(15)
+#undef AS_LN_STAGE
+            const long brow = (long)m0 + wm * 64 + i * 32 + lane;
+            if (lane < 32 && brow < g.M) reinterpret_cast<unsigned*>(g.bits)[(brow * g.batch + bz) * 8 + wn] = mine;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = acc[i][r];
+        }
+        lds_barrier();
+        if (4 * wave_u >= 32 * (n_groups_m1 + 1)) continue;     // (wave-uniform: more waves than groups of four staged rows)
+        const long row = (long)m0 + trow_base + i * 32;
+        f32x4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const f32x4*>(smem + srow * BN + 64 * c + 4 * jj);
+        float* o = g.C + (long)bz * g.c_batch + row * g.ldc + 4 * jj;
+        if (EPI == EPI_LNF) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+            const float mean = row16_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] -= mean;
+                q += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+            }
+            const float rs = 1.0f / sqrtf(row16_sum(q) * inv_d + g.eps);
+            if (row < g.M) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(o + 64 * c) = v[c] * rs;
+                if (jj == 0) g.rstd[row * g.batch + bz] = rs;
+            }
+        } else {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1 += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+                s2 += (v[c].x * h[i][c].x + v[c].y * h[i][c].y) + (v[c].z * h[i][c].z + v[c].w * h[i][c].w);
+            }
+            const float m1 = row16_sum(s1) * inv_d, m2 = row16_sum(s2) * inv_d;
+            if (row < g.M) {
+                const float rs = rs_in[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // mask word c (64 bits: features 64 c ..): this lane's four bits sit at 4 jj
+                    const unsigned lo = c == 0 ? mw[i][0].x : c == 1 ? mw[i][0].z : c == 2 ? mw[i][1].x : mw[i][1].z;
+                    const unsigned hi = c == 0 ? mw[i][0].y : c == 1 ? mw[i][0].w : c == 2 ? mw[i][1].y : mw[i][1].w;
+                    const unsigned nib = (jj < 8 ? lo : hi) >> (4 * (jj & 7));
+                    f32x4 d = (v[c] - m1 - h[i][c] * m2) * rs;
+                    d.x = (nib & 1u) ? d.x : 0.f;
+                    d.y = (nib & 2u) ? d.y : 0.f;
+                    d.z = (nib & 4u) ? d.z : 0.f;
+                    d.w = (nib & 8u) ? d.w : 0.f;
+                    *reinterpret_cast<f32x4*>(o + 64 * c) = d;
+                }
+            }
+        }
+    }
+}
+
 // ---- epilogue of the 256-column kernels (8 waves, wave w owns columns 32 w .. 32 w + 31 of all BM rows).
 // D[row][col]: col = wave * 32 + l31, row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh -- the accumulator layout of
 // v_mfma_f32_32x32x2_f32 and of v_mfma_f32_32x32x16_bf16 alike.  `smem`: >= 32 * BN floats, free of readers (behind a barrier).
@@ -127,85 +261,7 @@ __device__ __forceinline__ void lin_epilogue(const LinK& g, f32x16 (&acc)[TM], f
         return;
     }
     const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
-    constexpr float inv_d = 1.0f / BN;
-    // backward: everything this wave reads from global memory (x_hat rows, rstd, mask words of its 4 rows per 32-row
-    // block) is requested up front -- vector memory operations retire in order, so a load issued behind the first block's
-    // stores would wait for them
-    // (rstd and the mask words are wave-uniform: scalar loads, which do not queue behind the vector stores)
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    float h[TM][4][4];
-    if (EPI == EPI_LNB) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long row = min((long)m0 + i * 32 + wave_u + 8 * q, (long)g.M - 1);
-                const float* xr = g.xhat + (long)bz * g.x_batch + row * g.ldx;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) h[i][q][c] = xr[lane + 64 * c];
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {   // 32 rows at a time through 32 KB of LDS
-        if (i >= tm_eff) break;
-        if (i > 0) lds_barrier();    // the previous block's rows are all read
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[i][r] + bj;
-            if (EPI == EPI_LNF) v = as_relu(v);
-            smem[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = v;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // one wave per row; lane holds features lane + 64 c
-            const int rr = wave_u + 8 * q;
-            const long row = m0 + i * 32 + rr;
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = smem[rr * BN + lane + 64 * c];
-            float* o = g.C + (long)bz * g.c_batch + row * g.ldc;
-            if (EPI == EPI_LNF) {
-                unsigned long long pos[4];
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s += v[c];
-                    pos[c] = __ballot(v[c] > 0.f);
-                }
-                const float mean = wave_sum(s) * inv_d;
-                float qq = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    v[c] -= mean;
-                    qq += v[c] * v[c];
-                }
-                const float rs = 1.0f / sqrtf(wave_sum(qq) * inv_d + g.eps);
-                if (row < g.M) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[lane + 64 * c] = v[c] * rs;
-                    if (lane == 0) g.rstd[row * g.batch + bz] = rs;
-                    if (lane < 4) g.bits[(row * g.batch + bz) * 4 + lane] = lane == 0 ? pos[0] : lane == 1 ? pos[1] : lane == 2 ? pos[2] : pos[3];
-                }
-            } else {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s1 += v[c];
-                    s2 += v[c] * h[i][q][c];
-                }
-                const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
-                if (row < g.M) {
-                    const float rs = g.rstd_in[row * g.batch + bz];
-                    const unsigned long long* mw = g.bits_in + (row * g.batch + bz) * 4;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float d = rs * (v[c] - m1 - h[i][q][c] * m2);
-                        o[lane + 64 * c] = (mw[c] >> lane) & 1ull ? d : 0.f;
-                    }
-                }
-            }
-        }
-    }
+    lin_ln_rows<TM, EPI, 8>(g, acc, smem, bz, m0, tm_eff, 0, wave, lane, bj);
 }
 
 // NB ring slots: 3 (two k-tiles in flight, 60 KB: two workgroups per CU) or 2 (one in flight, 40 KB: three per CU; diagnostic)
@@ -442,8 +498,6 @@ __device__ __forceinline__ gptr uniform_ptr(const void* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<gptr>(((uintptr_t)hi << 32) | lo);
 }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
 
