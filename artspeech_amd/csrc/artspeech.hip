@@ -93,9 +93,6 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
 
 struct ModelWs {
     int64_t tokflag, tab0, y0, y0d, g0, xp1, y1, g1, lin, head, dy1, dgi1, dgh1, dy0, dgi0, dgh0, dtab0, total;
-    // GRU layer-1 input weights as bfloat16 planes (as_emit_planes)
-    int64_t wih1p;
-    int xp_bn;   // column block of the layer-1 input projection on the split-arithmetic kernel (256 | 128; 0 = not a case)
 };
 
 ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
@@ -118,11 +115,6 @@ ModelWs model_ws(const as_dims& d, int64_t B, int64_t T) {
         w.dgi0 = c.take(R * 6 * H);
         w.dgh0 = c.take(R * 6 * H);
         w.dtab0 = c.take(V * 6 * H);
-        // split-arithmetic GEMMs of the GRU side (H % 16 == 0: reductions of 2H and 6H in whole 32-deep k-tiles; 2H <= 256 columns)
-        w.xp_bn = (H % 16 == 0 && 2 * H <= 256) ? ((6 * H) % 256 == 0 ? 256 : ((6 * H) % 128 == 0 ? 128 : 0)) : 0;
-        if (w.xp_bn) {
-            w.wih1p = c.take(as_planes_floats((int)(6 * H / w.xp_bn), w.xp_bn, (int)(2 * H)));
-        }
     } else {
         w.tab0 = c.take(V * H);   // relu(Emb Wl^T + bl) per token
         w.dtab0 = c.take(V * H);
@@ -683,16 +675,6 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
         AS_TRY(head_fold(*d, L, P, R, ws + w.head, st));
         AS_TRY(as_count_bad_tokens(tokens, tok_stride, T, R, V, reinterpret_cast<int*>(ws + w.tokflag), st));
     }
-    const bool s6 = !d->simple && w.xp_bn && as_matrix_arith() == AS_ARITH_BF16X6;
-    if (s6) {
-        // GRU layer-1 input weights as bfloat16 planes: one small launch on the caller's stream (they depend on parameters the previous optimizer step on this stream has just written)
-        auto up = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
-        const int bn = w.xp_bn;
-        as_planes_job j[1] = {
-            {P + L.w_ih[1], 2L * H, 1, (long)bn * 2 * H, 6 * H / bn, bn, 2 * H, bn, 2 * H, up(w.wih1p)},
-        };
-        AS_STEP("gru.planes", st, as_emit_planes(j, 1, st));
-    }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
         if ((long)V * E <= 16384)   // the step's first kernel, on its critical path: a small dedicated kernel (rowops.hip)
@@ -722,19 +704,8 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
                 took = as_lin_try(&l, st);
                 AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
             }
-            if (!took && s6) {   // split arithmetic: 6H / bn column blocks of bn
-                const int bn = w.xp_bn;
-                as_lin l{};
-                l.A = l1_in; l.lda = 2 * H;
-                l.Bp = reinterpret_cast<const uint16_t*>(ws + w.wih1p); l.bp_rows = bn; l.bp_batch = as_planes_batch_stride(bn, 2 * H);
-                l.bp_plane = (6 * H / bn) * l.bp_batch;
-                l.C = ws + w.xp1; l.ldc = 6 * H; l.c_batch = bn;
-                l.bias = P + L.b_ih[1]; l.bias_batch = bn;
-                l.M = R; l.N = bn; l.K = 2 * H; l.batch = 6 * H / bn;
-                AS_PROF("gru.xproj1", st);
-                took = as_lin_plain_s6(&l, 1, 0, st);
-                AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
-            }
+            // (the split-arithmetic kernel was measured here too: 39.5 vs 43 us for the GEMM, but its weight planes cost a
+            // 10-us launch on this stream in front of the step's first kernel: net slower.  Not kept.)
             if (!took)
                 AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
         }

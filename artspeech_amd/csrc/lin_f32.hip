@@ -120,12 +120,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 // with v_readlane each and an IEEE 1 / sqrt per row, the four rows of a wave one after the other: 12 k cycles per 64-row
 // tile, as long as the split-arithmetic main loop.)
 //   NWC  column waves per row block (8).  Waves of row group wm = wave / NWC own tile rows wm * 64 + i * 32 + ...; the
-//        staging area holds one 32-row block per row group: [NG * 32][BN] floats, NG = number of row groups (1 | 2).
+//        staging area holds one 32-row block per row group: [groups * 32][BN] floats.  groups (1 | 2) = row groups that hold
+//        rows of the tile; tm_eff = their row blocks (a workgroup may have more waves than that: they only keep the barriers).
 //   EPI_LNF: x = relu(acc + bias); C = (x - mean) * rstd; rstd; bits (x > 0, one 32-bit piece per (row, column wave), taken
 //            from the accumulators by ballot before they leave for LDS).
 //   EPI_LNB: C = relu'(bits_in) * rstd_in * (acc - mean(acc) - xhat * mean(acc * xhat)).
 template <int TM, int EPI, int NWC>
-__device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], float* smem, int bz, int m0, int tm_eff, int n_groups_m1, int wave,
+__device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], float* smem, int bz, int m0, int tm_eff, int groups, int wave,
                                             int lane, float bj) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -136,12 +137,13 @@ __device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], fl
     // staged row of this lane in the normalisation phase: 4 * wave + rr of the NG * 32 staged rows; its tile row
     const int srow = 4 * wave_u + rr;
     const int trow_base = (srow >> 5) * 64 + (srow & 31);      // + i * 32
+    const bool stages = wm < groups, normalises = 4 * wave_u < 32 * groups;   // (wave-uniform)
     // backward: everything this wave reads from global memory is requested up front (vector memory operations retire in
     // order: a load issued behind the first block's stores would wait for them)
     f32x4 h[TM][4];
     float rs_in[TM];
     u32x4 mw[TM][2];
-    if (EPI == EPI_LNB) {
+    if (EPI == EPI_LNB && normalises) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long row = min((long)m0 + trow_base + i * 32, (long)g.M - 1);
@@ -159,7 +161,8 @@ __device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], fl
         if (i >= tm_eff) break;
         if (i > 0) lds_barrier();    // the previous block's rows are all read
         float* st = smem + wm * 32 * BN;
-        if (EPI == EPI_LNF) {
+        if (!stages) {
+        } else if (EPI == EPI_LNF) {
             unsigned mine = 0;        // lane L < 32: the mask piece (columns 32 wn .. 32 wn + 31) of block row L
             // (v_writelane_b32 with the lane as an immediate: one instruction per piece -- a compare + select per piece would be
             // four, and two scalar operands violate the constant-bus limit -- hence a macro over the literal register index)
@@ -183,7 +186,7 @@ __device__ __forceinline__ void lin_ln_rows(const LinK& g, f32x16 (&acc)[TM], fl
             for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lh) * BN + col] = acc[i][r];
         }
         lds_barrier();
-        if (4 * wave_u >= 32 * (n_groups_m1 + 1)) continue;     // (wave-uniform: more waves than groups of four staged rows)
+        if (!normalises) continue;
         const long row = (long)m0 + trow_base + i * 32;
         f32x4 v[4];
 #pragma unroll
@@ -261,7 +264,7 @@ __device__ __forceinline__ void lin_epilogue(const LinK& g, f32x16 (&acc)[TM], f
         return;
     }
     const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
-    lin_ln_rows<TM, EPI, 8>(g, acc, smem, bz, m0, tm_eff, 0, wave, lane, bj);
+    lin_ln_rows<TM, EPI, 8>(g, acc, smem, bz, m0, tm_eff, 1, wave, lane, bj);
 }
 
 // NB ring slots: 3 (two k-tiles in flight, 60 KB: two workgroups per CU) or 2 (one in flight, 40 KB: three per CU; diagnostic)
@@ -590,9 +593,16 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
     lds_barrier();
     if (stamp1) *stamp1 = __builtin_amdgcn_s_memtime();
     // k-tile kt (kt % 3 == U): its plane image is in buffer kt & 1, its B fragments in sets (2 kt) % 3 and (2 kt + 1) % 3
+#ifdef AS_S6_TRACE   // diagnostic build: per-tile cycle stamps of every wave of the stamped workgroups (tools/s6_trace.py)
+    unsigned long long* tr = stamp1 ? stamp1 - 1 + 8L * 4096 + ((long)blockIdx.x * 8 + (tid >> 6)) * 64 : nullptr;
+#define AS_TR(slot) if (tr && lane == 0) tr[(kt < 10 ? kt : 9) * 6 + (slot)] = __builtin_amdgcn_s_memtime();
+#else
+#define AS_TR(slot)
+#endif
     auto tile = [&](auto Uc, int kt) {
         constexpr int U = decltype(Uc)::value;
         const unsigned char* img = a_rd + (abl == 5 ? 0 : (kt & 1) * S6_BUF);
+        AS_TR(0)
         if (abl != 3) a_load(aq[(U + 2) % 3], kt + 2);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -605,6 +615,7 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
                 for (int i = 0; i < TME; ++i)
                     fa[i][p] = *reinterpret_cast<const bf16x8*>(img + p * S6_PLANE + i * 32 * 64 + (((2 * s + lh) ^ sw) * 16));
             const u32x4(&bs)[3] = bq[(2 * U + s) % 3];
+            if (s == 0) { AS_TR(1) }
             bf16x8 fb[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fb[p] = __builtin_bit_cast(bf16x8, bs[p]);
@@ -623,10 +634,14 @@ __device__ __forceinline__ void s6_main_loop(f32x16 (&acc)[2], unsigned char* sm
             // the workgroup: waves 0-3 behind the tile's second k-step, waves 4-7 between the two.  Waves w and w + 4 share a
             // SIMD and, running the same program between the same barriers, would otherwise do their vector work at the same
             // moment and their matrix work at the same moment -- the matrix pipe idles through the former.
+            if (s == 0) { AS_TR(2) } else { AS_TR(3) }
             if (abl != 3 && late == (s == 0)) a_store(aq[(U + 1) % 3], (kt & 1) ^ 1);   // (behind the last tile: a clamped repeat)
         }
+        AS_TR(4)
         lds_barrier();
+        AS_TR(5)
     };
+#undef AS_TR
     int kt = 0;
     for (; kt + 3 <= nk; kt += 3) {
         tile(IC<0>{}, kt);
@@ -690,6 +705,154 @@ __global__ __launch_bounds__(NT, 4) void lin_s6_kernel(LinK g) {
         d[3] = __builtin_amdgcn_s_memtime();
         d[6] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The wide form of lin_s6_kernel: ONE workgroup of 16 waves per CU owns 128 rows x 256 columns (two row groups of 8 column
+// waves; wave = 64 rows x 32 columns as before) and the weight planes go through the LDS too, staged once per workgroup.
+// Why: the 64-row kernel's main loop is bound by what the CUs pull from L2, not by the matrix pipe -- every wave loads its
+// own B fragments, 24 KB per 64 rows and 16-deep k-step, 432 MB per launch of head Linear 2 against 72 MB of activations;
+// removing the matrix instructions from that loop changed its time by 4 % (profiles/r04_s6_ablation.log).  Here a k-tile's
+// planes (48 KB) are fetched once per 128 rows: a quarter of the bytes per row.  LDS: two A images (2 x 24 KB) + two B
+// images (2 x 48 KB) = 144 KB; one barrier per 32-deep k-tile; A two tiles ahead in registers, B one tile ahead (load at the
+// top of a tile, ds_write_b128 at its end: one register set).  The epilogue stages 64 rows at a time ([64][256] floats in the
+// images' memory), every wave normalising four rows (lin_ln_rows).
+// Tile list: 128-row tiles first (whole rounds of one workgroup per CU), then 32-row tiles over the remaining rows (row group
+// 0 multiplies one row block, row group 1 only helps with the loads): the partly filled last round costs a third of a tile.
+constexpr int SW_NT = 1024;
+constexpr int SW_AIMG = 3 * 128 * 64;      // bytes of one A image: 3 planes x 128 rows x 32 bf16
+constexpr int SW_BIMG = 3 * 256 * 64;      // bytes of one B image: 3 planes x 256 rows x 32 bf16
+constexpr int SW_LDS = 2 * SW_AIMG + 2 * SW_BIMG;
+
+template <int TME>   // row blocks of 32 this wave multiplies per k-step: 2 (128-row tile), 1 (32-row tile, row group 0), 0 (loads only)
+__device__ __forceinline__ void s6w_main_loop(f32x16 (&acc)[2], unsigned char* sm, const float* __restrict__ A, long lda, int rows_valid, int K,
+                                              int ka_valid, const uint16_t* __restrict__ bp, long bp_plane, int bp_rows, int tid, int lane,
+                                              int wm, int wn, bool late) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    // A: thread -> row tid >> 3 (0..127), 16-byte chunk tid & 7 of the row's 32 k
+    const int a_row = tid >> 3, a_chunk = tid & 7;
+    const unsigned a_off = (unsigned)(min(a_row, rows_valid - 1) * (int)lda + a_chunk * 4) * 4u;   // bytes
+    const int a_wr = a_row * 64 + (((a_chunk >> 1) ^ ((a_row >> 2) & 3)) * 16) + (a_chunk & 1) * 8;
+    // B: thread -> image row tid >> 2 (0..255), chunk tid & 3 = 8 consecutive k (k-step chunk >> 1, half chunk & 1)
+    const int b_row = tid >> 2, b_chunk = tid & 3;
+    const unsigned b_off = (unsigned)((((b_chunk >> 1) * bp_rows + b_row) * 16 + (b_chunk & 1) * 8) * 2);   // bytes
+    const int b_wr = b_row * 64 + ((b_chunk ^ ((b_row >> 2) & 3)) * 16);
+    const int nk = K / S6_BK;
+    const gptr Au = uniform_ptr(A);
+    const long bp_tile = 2L * bp_rows * 16;     // elements per 32-deep k-tile of one plane
+    auto a_load = [&](f32x4& dst, int kt) {
+        kt = min(kt, nk - 1);
+        const unsigned ko = kt * S6_BK + a_chunk * 4 + 4 <= ka_valid ? (unsigned)(kt * S6_BK) * 4u : 0u - (unsigned)a_chunk * 16u;
+        dst = *reinterpret_cast<gptr_f4>(Au + (a_off + ko));
+    };
+    auto a_store = [&](const f32x4& src, int buf) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_pair(src.x, src.y, h0, m0, l0);
+        split_pair(src.z, src.w, h1, m1, l1);
+        unsigned char* d = sm + buf * SW_AIMG + a_wr;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 128 * 64) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 2 * 128 * 64) = make_uint2(l0, l1);
+    };
+    auto b_load = [&](u32x4 (&dst)[3], int kt) {
+        kt = min(kt, nk - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<gptr_u4>(uniform_ptr(bp + p * bp_plane + kt * bp_tile) + b_off);
+    };
+    auto b_store = [&](const u32x4 (&src)[3], int buf) {
+        unsigned char* d = sm + 2 * SW_AIMG + buf * SW_BIMG + b_wr;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(d + p * 256 * 64) = src[p];
+    };
+    const int sw = (l31 >> 2) & 3;
+    const unsigned char* a_rd = sm + (wm * 64 + l31) * 64;
+    const unsigned char* b_rd = sm + 2 * SW_AIMG + (wn * 32 + l31) * 64;
+
+    f32x4 aq[2];
+    u32x4 bq[3];
+    a_load(aq[0], 0);
+    b_load(bq, 0);
+    a_load(aq[1], 1);
+    a_store(aq[0], 0);
+    b_store(bq, 0);
+    lds_barrier();
+    // k-tile kt: images in buffers kt & 1; registers aq[(kt + 1) & 1] hold A of tile kt + 1
+    auto tile = [&](auto Uc, int kt) {
+        constexpr int U = decltype(Uc)::value;   // kt & 1
+        b_load(bq, kt + 1);
+        f32x4 a_next;
+        a_load(a_next, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ai = a_rd + U * SW_AIMG;
+        const unsigned char* bi = b_rd + U * SW_BIMG;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (TME > 0) {
+                bf16x8 fa[TME > 0 ? TME : 1][3], fb[3];
+                const int ch = ((2 * s + lh) ^ sw) * 16;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TME; ++i) fa[i][p] = *reinterpret_cast<const bf16x8*>(ai + p * 128 * 64 + i * 32 * 64 + ch);
+                    fb[p] = *reinterpret_cast<const bf16x8*>(bi + p * 256 * 64 + ch);
+                }
+                constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int o = 0; o < 6; ++o)
+#pragma unroll
+                    for (int i = 0; i < TME; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[PB[o]], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next tile's images are written between the two k-steps by half of the waves and behind the second by the other
+            // half (SIMD partners then do their vector / LDS-store work at different moments, see s6_main_loop)
+            if (late == (s == 0)) {
+                a_store(aq[U ^ 1], U ^ 1);
+                b_store(bq, U ^ 1);
+            }
+        }
+        aq[U] = a_next;
+        lds_barrier();
+    };
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        tile(IC<0>{}, kt);
+        tile(IC<1>{}, kt + 1);
+    }
+    if (kt < nk) tile(IC<0>{}, kt);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(SW_NT, 4) void lin_s6w_kernel(LinK g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+    int bz, m0, rows;
+    const int tile = blockIdx.x;
+    if (tile < g.n_big) {
+        bz = tile / g.big_per_batch;
+        m0 = (tile - bz * g.big_per_batch) * 128;
+        rows = 128;
+    } else {
+        const int j = tile - g.n_big;
+        bz = j / g.small_per_batch;
+        m0 = g.big_per_batch_rows + (j - bz * g.small_per_batch) * 32;
+        rows = 32;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_u >> 3, wn = wave_u & 7;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const uint16_t* bp = g.Bp + (long)bz * g.bp_batch;
+    const float* A = g.A + (long)bz * g.a_batch + (long)m0 * g.lda;
+    const bool late = (wave_u >> 2) & 1;
+    if (rows == 128) s6w_main_loop<2>(acc, smw, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, g.bp_plane, g.bp_rows, tid, lane, wm, wn, late);
+    else if (wm == 0) s6w_main_loop<1>(acc, smw, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, g.bp_plane, g.bp_rows, tid, lane, wm, wn, late);
+    else s6w_main_loop<0>(acc, smw, A, g.lda, g.M - m0, g.K, g.ka_valid, bp, g.bp_plane, g.bp_rows, tid, lane, wm, wn, late);
+    const int col = wn * 32 + (lane & 31);
+    const float bj = (EPI == EPI_LNF && g.bias) ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+    lin_ln_rows<2, EPI, 8>(g, acc, reinterpret_cast<float*>(smw), bz, m0, rows == 128 ? 2 : 1, rows == 128 ? 2 : 1, wave, lane, bj);
 }
 
 // A plain Linear on the same main loop: C = act(A . B^T + bias), 64 (or 32) rows x 32 NW columns per workgroup (NW = 8:
@@ -1103,6 +1266,36 @@ int launch(const LinK& k, hipStream_t st) {
     kk.small_per_batch = as_cdiv(rest, 32);
     const long total = (long)kk.n_big + (long)kk.small_per_batch * k.batch;
     if (kk.small_per_batch == 0) kk.small_per_batch = 1;
+    if (kk.Bp && EPI != EPI_PLAIN && k.tile_rows == 0 && (long)as_cdiv(k.M, 128) * k.batch >= 256 && k.bp_rows == BN) {
+        // at least one whole round of 128-row tiles: the wide kernel (one 16-wave workgroup per CU, B planes through LDS)
+        // MEASURED SLOWER than the 64-row kernel (head Linear 2: 77.5 vs 63.4 us, dx2 86.5 vs 80.2 us, gpurun_out/r04a): all 16
+        // waves of the CU meet at one barrier per k-tile, and a workgroup alone on its CU keeps the matrix pipe about half busy
+        // (per-tile stamps, tools/s6_trace.py: ~1000 cycles until a tile's first fragments are in registers, ~900 at the barrier,
+        // ~550 in the split, against 768 of matrix instructions per wave) -- two independent 8-wave workgroups fill each
+        // other's gaps, one 16-wave workgroup does not.  Kept for the diagnostic build only (AS_LIN_WIDE=1).
+        static const bool wide = AS_DIAG_SET("AS_LIN_WIDE");
+        if (wide) {
+            static const hipError_t attr =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(lin_s6w_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+            if (attr != hipSuccess) {
+                as_set_error("as_lin_s6w: cannot reserve %d bytes of LDS: %s", SW_LDS, hipGetErrorString(attr));
+                return (int)attr;
+            }
+            const long t128 = (long)(k.M / 128) * k.batch;          // whole 128-row tiles
+            int xw = (int)((t128 / 256) * 256 / k.batch);            // ... per head that fill whole rounds of the 256 CUs
+            if (xw > k.M / 128) xw = k.M / 128;
+            const int restw = k.M - xw * 128;
+            kk.big_per_batch = xw > 0 ? xw : 1;
+            kk.big_per_batch_rows = xw * 128;
+            kk.n_big = xw * k.batch;
+            kk.small_per_batch = as_cdiv(restw, 32);
+            const long totalw = (long)kk.n_big + (long)kk.small_per_batch * k.batch;
+            if (kk.small_per_batch == 0) kk.small_per_batch = 1;
+            hipLaunchKernelGGL((lin_s6w_kernel<EPI>), dim3((unsigned)totalw), dim3(SW_NT), SW_LDS, st, kk);
+            AS_LAUNCH_CHECK("as_lin_s6w");
+            return 0;
+        }
+    }
     if (kk.Bp) {   // the products on the bf16 matrix instruction, B as planes (lin_s6_kernel)
         hipLaunchKernelGGL((lin_s6_kernel<EPI>), dim3((unsigned)total), dim3(NT), 0, st, kk);
         AS_LAUNCH_CHECK("as_lin_s6");
