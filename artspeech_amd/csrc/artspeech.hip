@@ -78,7 +78,8 @@ HeadWs head_ws(const as_dims& d, int64_t rows) {
     w.slab3 = c.take(SLAB_FLOATS);  // same, second side stream
     w.bits1 = c.take(rows * A * (D / 64) * 2);  // ReLU masks of r1 / r2: one bit per element (64-bit words, 16-byte aligned)
     w.bits2 = c.take(rows * A * (D / 64) * 2);
-    w.lpart_n = (rows / 32 + 2) * A;      // workgroup partial sums of the fused criterion (one per output-layer tile)
+    // workgroup partial sums of the fused criterion (one per output-layer tile), or of the separate criterion kernel
+    w.lpart_n = std::max<int64_t>((rows / 32 + 2) * A, as_euclid_masked_partials());
     w.lpart = c.take(w.lpart_n);
     const int Opad = (int)as_round_up(O, 32);
     w.w1p = c.take(as_planes_floats((int)A, D, (int)as_round_up(H, 32)));
@@ -226,6 +227,7 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
         l1.Bp = w1p; l1.bp_rows = D; l1.bp_batch = as_planes_batch_stride(D, H); l1.bp_plane = A * l1.bp_batch;
     }
     int took;
+    bool crit_done = false;
     {
         AS_PROF("head.gemm1", st);
         took = as_lin_try(&l1, st);
@@ -278,8 +280,8 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
         }
         took = as_lin_out_try(&lo, &n_part, st);
         AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
-        AS_REQUIRE(took || !crit, AS_ERR_UNSUPPORTED, "as_artspeech_fwd: the fused criterion needs 2 N <= 128 outputs per head (N = %d)", d.n_samp);
         if (took && crit) AS_TRY(as_loss_final(ws + w.lpart, n_part, crit->scale, crit->loss, st));
+        crit_done = took && crit;
         if (!took) {
             took = as_lin_try(&l3, st);
             AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
@@ -288,6 +290,12 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
     if (!took)
         AS_STEP("head.gemm3", st, gemm_nt(ws + w.r2hat, AD, ws + w.w3f, D, out, (long)A * O, ws + w.b3f, R, O, D, 2, st, A, D,
                        (long)Opad * D, O, O));
+    if (crit && !crit_done) {
+        // the output-layer kernel declined (more than 128 outputs per head, fewer than 4, odd strides): the criterion as its own
+        // kernel on the stored contours -- same loss, same d loss / d(pre-sigmoid), one pass more
+        AS_STEP("loss", st, as_euclid_masked_fwd_bwd_presigmoid(out, crit->tgt, crit->tgt_T, crit->lengths, (int32_t)(rows / crit->T), crit->T, A,
+                                                               d.n_samp, crit->scale, crit->loss, crit->dout, ws + w.lpart, st));
+    }
     return 0;
 }
 
@@ -677,7 +685,9 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
     }
     if (!d->simple) {
         // token table of layer-0 input projections, both directions: [V][2][3H]
-        if ((long)V * E <= 16384)   // the step's first kernel, on its critical path: a small dedicated kernel (rowops.hip)
+        // the step's first kernel, on its critical path: a small dedicated kernel (rowops.hip) while its staging area --
+        // (4 E + 64 (E + 1)) floats of dynamic LDS -- stays inside the 64 KB a launch gets without asking (E <= 240)
+        if ((long)V * E <= 16384 && ((size_t)4 * E + 64 * ((size_t)E + 1)) * sizeof(float) <= 65536)
             AS_STEP("gru.table0", st, as_token_table(P + L.embedding, P + L.w_ih[0], P + L.b_ih[0], V, 6 * H, E, ws + w.tab0, st));
         else
             AS_STEP("gru.table0", st, gemm_nt(P + L.embedding, E, P + L.w_ih[0], E, ws + w.tab0, 6 * H, P + L.b_ih[0], V, 6 * H, E, 0, st));

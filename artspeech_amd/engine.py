@@ -63,8 +63,10 @@ class TrainStep:
         self.steps = 0
         self.bwd_opts = _lib.Opts(0.0, 0, 1, 1 if self.pipeline else 0, None)
         self.fwd_opts = _lib.Opts(0.0, 0, 0, 0, None)
-        # criterion fused into the output layer of the heads (as_opts.loss_*): needs 2 N <= 128 outputs per head
-        self.fuse_loss = 2 * d.n_samp <= 128
+        # criterion handed to the forward (as_opts.loss_*): fused into the output layer of the heads where that kernel takes
+        # the shape (2 N <= 128 outputs per head, ...), else run by the library as its own kernel -- either way the forward
+        # leaves the loss and d loss / d(pre-sigmoid)
+        self.fuse_loss = True
         if self.pipeline:
             self.late_stream = torch.cuda.Stream(device=dev)
             self.late_event = torch.cuda.Event()

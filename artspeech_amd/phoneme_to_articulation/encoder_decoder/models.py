@@ -113,7 +113,9 @@ class _ArtSpeechFn(torch.autograd.Function):
         if defer is None:
             _raise_if_bad_tokens(ws, dims.vocab)
         else:
-            defer.append(ws)   # a loop that synchronises anyway (loss.item()) calls model.check_tokens() there
+            # a loop that synchronises anyway (loss.item()) calls model.check_tokens() there.  Only the flag word is kept (a
+            # 4-byte copy): holding the workspace itself would pin ~1 GB per batch until the check
+            defer.append(ws[:1].clone())
         if train:
             ctx.save_for_backward(flat, tokens, lengths_dev, out, ws)
             ctx.meta = (dims, B, T, opts)

@@ -333,7 +333,9 @@ int as_pearson_fwd(const float* out, int64_t out_b, int64_t out_t, const float* 
  * segments of the frame's contours [A][2][N] concatenated.
  *   spec: int32 [n_tv][3 segments][3] = {channel, start, end} for arr1, arr2 part 1, arr2 part 2
  *         (channel < 0 => segment absent), on the DEVICE.
- *   values [frames][n_tv], poc1/poc2 [frames][n_tv][2], idx int32 [frames][n_tv][2] (may be NULL). */
+ *   values [frames][n_tv], poc1/poc2 [frames][n_tv][2], idx int32 [frames][n_tv][2] (may be NULL).
+ * Limits: N <= 64 points per contour (a lane owns one arr2 point; the reference's slices hold 15 .. 50, n_samples = 50) and
+ * a frame [A][2][N] of at most ~15 K floats (it is staged in LDS once): AS_ERR_UNSUPPORTED beyond. */
 int as_tract_variables_fwd(const float* contours, int64_t frames, int32_t A, int32_t N, const int32_t* spec,
                            int32_t n_tv, float* values, float* poc1, float* poc2, int32_t* idx, void* stream);
 

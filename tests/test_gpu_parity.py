@@ -812,6 +812,38 @@ def test_artspeech_vs_oracle_more_than_1024_frames(dev, V):
         assert_grad_close(v, og[k], f"1280 frames, V={V}, vs oracle (ReLU decisions taken from the device: {flips}): {k}")
 
 
+@pytest.mark.parametrize("E", [256, 320])
+def test_artspeech_wide_embeddings_vs_oracle(dev, E):
+    """embed_dim 256 / 320 with V = 45: V * E is small enough for the dedicated token-table kernel, but its staging area
+    ((4 E + 64 (E + 1)) floats) would exceed the 64 KB of LDS a launch gets without asking -- such widths take the general GEMM
+    (as_artspeech_fwd's gate is on the bytes, not on V * E alone).  Contours and gradients against the oracle."""
+    from artspeech_amd.phoneme_to_articulation.encoder_decoder.models import ArtSpeech
+    from artspeech_amd.phoneme_to_articulation.metrics import masked_euclidean_loss
+    torch.manual_seed(E)
+    V, A = 45, 2
+    model = ArtSpeech(V, A, embed_dim=E, hidden_size=64)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, T = 3, 21
+    lengths = np.array([21, 13, 2])
+    rng = np.random.RandomState(E)
+    x = rng.randint(1, V, (B, T))
+    tgt = rng.rand(B, T, A, 2, 50).astype(np.float32)
+    for b, l in enumerate(lengths):
+        x[b, l:] = 0
+        tgt[b, l:] = 0
+    out = model(T_(x, dev, torch.int64), torch.from_numpy(lengths))
+    loss = masked_euclidean_loss(out, T_(tgt, dev), lengths)
+    loss.backward()
+    o_out, cache = O.artspeech_fwd(sd, x, lengths, A)
+    assert_close(out.detach().cpu().numpy(), o_out, what=f"contours, E={E}")
+    o_loss, o_dout = O.masked_euclid_loss(o_out, tgt, lengths)
+    assert abs(loss.item() - o_loss) < 1e-6
+    og = O.artspeech_bwd(o_dout, cache, A)
+    for k, v in model.named_grad_views().items():
+        assert_grad_close(v.cpu().numpy(), og[k], f"E={E} vs oracle: {k}")
+
+
 @pytest.mark.parametrize("H", [48, 256, 36])
 def test_artspeech_other_hidden_sizes_vs_oracle(dev, H):
     """The reference accepts any hidden size (encoder_decoder/models.py:100-111); sizes outside {32, 64, 128} run the plain

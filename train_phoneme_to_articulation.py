@@ -71,8 +71,20 @@ def run_epoch(phase, epoch, model, dataloader, optimizer, criterion, fn_metrics=
     # reduction "none" (the training configuration): criterion + mask + mean collapse into one kernel
     fused = isinstance(criterion, EuclideanDistance) and getattr(torch, criterion.reduction_name, None) is None
     deferred = hasattr(model, "check_tokens")   # token-id check next to the loop's own loss.item() instead of a sync per forward
+    keep_defer = getattr(model, "defer_token_check", False)
     if deferred:
-        model.defer_token_check = True
+        model.defer_token_check = True          # for this loop only: restored below, whatever happens
+    try:
+        return _run_epoch_batches(phase, model, dataloader, optimizer, criterion, fn_metrics, scheduler, device, training, rank, world,
+                                  losses, metrics_values, fused, deferred)
+    finally:
+        if deferred:
+            model.defer_token_check = keep_defer
+            model.check_tokens()                # nothing stays pending (and an id outside the vocabulary still raises)
+
+
+def _run_epoch_batches(phase, model, dataloader, optimizer, criterion, fn_metrics, scheduler, device, training, rank, world, losses,
+                       metrics_values, fused, deferred):
     for _, sentence, targets, lengths, _, _, _, _ in dataloader:
         n_valid_global = int(lengths.sum())
         if world > 1:  # every rank sees the same global batch (same sampler seed) and keeps its shard
