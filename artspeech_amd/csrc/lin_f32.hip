@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "gemm_internal.h"
+#include "split_arith.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -476,22 +477,6 @@ __global__ __launch_bounds__(NT, NB == 2 ? 6 : 4) void lin_f32_kernel(LinK g) {
 //     {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} -- then touch each of the 64 banks once).  All eight
 //     waves read their A fragments from there: one barrier per 32-deep k-tile, two plane images (24 KB).
 //   * accumulator layout = that of the fp32 instruction: the LayerNorm epilogues above are shared.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 numbers -> three words of packed bfloat16 pairs (element a in the low half)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    f32x2 v = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v.x -= __uint_as_float(hi << 16);
-    v.y -= __uint_as_float(hi & 0xffff0000u);
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v.x -= __uint_as_float(mid << 16);
-    v.y -= __uint_as_float(mid & 0xffff0000u);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
 // a pointer the compiler must treat as wave-uniform (SGPR pair): base of the scalar-base form of a global load, whose lane
 // part is then a 32-bit byte offset.  (Without it hipcc re-associates base + lane offset into a loop-invariant 64-bit VECTOR
 // address and adds the uniform per-step part to that: two address registers and a 64-bit vector add per load.)

@@ -28,8 +28,10 @@
 #include <cstdlib>
 
 #include "gemm_internal.h"
+#include "split_arith.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -100,8 +102,18 @@ struct WgradMulti {
 };
 
 // SK: the stream-K instantiation (mm.streamk launches); the plain one compiles to a single pass of the segment loop.
-template <int BN, int BK, bool SK = false>
+// S6 (BK = 32): the products on the bfloat16 matrix instruction (as_set_matrix_arith(1): three planes per operand, six plane
+//   products per fp32 product, fp32 accumulation; see lin_f32.hip).  The fp32 image in LDS stays as it is ([k][m]: what the
+//   DMA delivers); a lane's MFMA fragment -- 8 consecutive frames of one column -- is read down the image (8 ds_read_b32,
+//   conflict-free) and split in registers (36 vector instructions).  Every wave splits the fragments it multiplies: the A
+//   block of a wave is split by the four waves that share its rows, the B block by two -- redundant vector work, but no
+//   second LDS image (the ring already takes 144 KB) and no extra barrier.  The split of k-step s + 1 is interleaved with
+//   the matrix instructions of k-step s (about seven vector instructions fit under one 32-cycle MFMA), and the barrier
+//   that publishes k-tile t + 1 sits in the MIDDLE of tile t, so that the first fragments of t + 1 are split under the second
+//   half of t's matrix work.  Per 32-frame k-tile a wave issues 48 MFMAs of 32 cycles instead of 64 of 64.
+template <int BN, int BK, bool SK = false, bool S6 = false>
 __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMulti mm) {
+    static_assert(!S6 || BK == 32, "split arithmetic: 32-deep k-tiles");
     constexpr int WN = BN / 4, TN = WN / 32, TM = 2;   // 2 x 4 waves; a wave owns 64 rows x WN columns
     constexpr int TILE = BK * (BM + BN);                // floats per ring slot: A image [BK][BM] then B image [BK][BN]
     constexpr int PA = BK * BM / 256 / 8;               // 1-KiB DMA pieces of A per wave and k-tile (2)
@@ -213,6 +225,89 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
     constexpr int CSRB = BK / (NT / BN);
 
     const int nk = (kend - kbeg) / BK;
+    if constexpr (S6) {
+        struct Fr { bf16x8 p[3]; };
+        // fragment of column `col` (pointer to its element in row 0 of the image), rows 16 s + 8 lh .. + 7
+        auto frag = [&](const float* col, int ld, int s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = col[(16 * s + 8 * lh + e) * ld];
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
+            Fr f;
+            f.p[0] = __builtin_bit_cast(bf16x8, (u32x4w){h[0], h[1], h[2], h[3]});
+            f.p[1] = __builtin_bit_cast(bf16x8, (u32x4w){m[0], m[1], m[2], m[3]});
+            f.p[2] = __builtin_bit_cast(bf16x8, (u32x4w){l[0], l[1], l[2], l[3]});
+            return f;
+        };
+        auto load_frags = [&](Fr (&fa)[TM], Fr (&fb)[TN], int kt, int s) {
+            const float* tile = smem + (kt % NBUF) * TILE;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = frag(tile + wm * 64 + i * 32 + l31, BM, s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = frag(tile + BK * BM + wn * WN + j * 32 + l31, BN, s);
+        };
+        auto mma = [&](const Fr (&fa)[TM], const Fr (&fb)[TN]) {
+            constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {0, 1, 2, 0, 1, 0};   // without mid.lo, lo.mid, lo.lo
+#pragma unroll
+            for (int o = 0; o < 6; ++o)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].p[PA[o]], fb[j].p[PB[o]], acc[i][j], 0, 0, 0);
+        };
+        // one MFMA, then the vector / LDS instructions that fit under it: the scheduler interleaves the next k-step's split
+        auto interleave = [&]() {
+#pragma unroll
+            for (int q = 0; q < 6 * TM * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Fr fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        load_frags(fa0, fb0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // slot (kt + 2) % 3 was last read (k-step 1 of tile kt - 1) before the barrier in the middle of tile kt - 1
+            if (kt + 2 < nk && g.abl != 1) issue(kt + 2);
+            const float* tile = smem + (kt % NBUF) * TILE;
+            if (do_cs) {
+                const float* c_s = tile + (tid >> 7) * CSR * BM + (tid & 127);
+#pragma unroll
+                for (int r = 0; r < CSR; ++r) cs += c_s[r * BM];
+            }
+            if (do_csb) {
+                const float* c_s = tile + BK * BM + (tid / BN) * CSRB * BN + (tid % BN);
+#pragma unroll
+                for (int r = 0; r < CSRB; ++r) csb += c_s[r * BN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            load_frags(fa1, fb1, kt, 1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            // retire tile kt + 1 (leave kt + 2 in flight) and publish it; this wave's reads of tile kt are all issued
+            if (kt + 2 < nk && g.abl != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mma(fa1, fb1);
+            if (kt + 1 < nk) {
+                load_frags(fa0, fb0, kt + 1, 0);
+                interleave();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the bias-gradient exchange below reuses the ring's memory
+    } else {
     // Ring of NBUF = 3 slots: while k-tile t is multiplied, t + 1 and t + 2 are in flight (2 x 48 KB per CU at BN = 256).
     // A counted vmcnt retires tile t + 1 at the END of iteration t (it was issued at the start of iteration t - 1: two
     // iterations of matrix work to land), then a raw barrier publishes it; __syncthreads() would drain every DMA.
@@ -265,6 +360,7 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : 2) void wgrad_f32_kernel(WgradMu
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of slot kt % 3 are done
         __builtin_amdgcn_s_barrier();
     }
+    }   // !S6
 
     // ---- bias gradient: the four row groups of a column meet in LDS, summed in a fixed order
     if (do_cs) {
@@ -477,8 +573,11 @@ bool describe(const as_gemm* g, WgradK& k) {
 template <int BNT>
 int launch_multi(WgradMulti& mm, int bk, hipStream_t st) {
     const dim3 grid((unsigned)(8 * mm.per_xcd));
-    if (mm.streamk) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true>), grid, dim3(NT), 0, st, mm);
+    const bool s6 = as_matrix_arith() == AS_ARITH_BF16X6 && bk == 32;
+    if (mm.streamk && s6) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true, true>), grid, dim3(NT), 0, st, mm);
+    else if (mm.streamk) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true>), grid, dim3(NT), 0, st, mm);
     else if (bk == 16) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 16>), grid, dim3(NT), 0, st, mm);
+    else if (s6) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, false, true>), grid, dim3(NT), 0, st, mm);
     else hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32>), grid, dim3(NT), 0, st, mm);
     AS_LAUNCH_CHECK("as_gemm_f32(wgrad)");
     if (mm.streamk) {
