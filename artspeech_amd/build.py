@@ -27,6 +27,7 @@ SOURCES = {
     "gemm_f32.hip": [],
     "wgrad_f32.hip": [],
     "lin_f32.hip": [],
+    "gemm_s6.hip": [],
     "rowops.hip": [],
     "gru.hip": [],
     "lstm.hip": [],

@@ -433,7 +433,7 @@ int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t ro
         int took = 0;
         if (multi_ok) {
             AS_PROF(part == 0 ? "headb.dw_fused" : "headb.dw31", st);
-            took = as_wgrad_multi(jobs, n, slab, slab_floats, cu_budget, st);
+            took = as_wgrad_multi(jobs, n, slab, slab_floats, cu_budget, st, cu_budget > 0);   // (beside a recurrence: exact, see gemm_internal.h)
             AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
         }
         if (!took) {
@@ -448,7 +448,7 @@ int head_bwd_dw(const as_dims& d, const as_layout& L, const float* P, int64_t ro
         int took = 0;
         if (multi_ok) {
             AS_PROF("headb.dw2", st);
-            took = as_wgrad_multi(&job2, 1, slab, slab_floats, cu_budget, st);
+            took = as_wgrad_multi(&job2, 1, slab, slab_floats, cu_budget, st, cu_budget > 0);
             AS_REQUIRE(took >= 0, took, "head weight gradients: launch failed");
         }
         if (!took)
@@ -714,15 +714,15 @@ extern "C" int as_artspeech_fwd(const as_dims* d, const float* P, const int64_t*
                 took = as_lin_try(&l, st);
                 AS_REQUIRE(took >= 0, took, "gru.xproj1: launch failed");
             }
-            // (the split-arithmetic kernel was measured here too: 39.5 vs 43 us for the GEMM, but its weight planes cost a
-            // 10-us launch on this stream in front of the step's first kernel: net slower.  Not kept.)
+            // (split arithmetic measured here twice and not kept: the plane-fed kernel of the heads 39.5 vs 43 us + a 10-us plane
+            // launch in front of the step's first kernel; both operands split in the kernel, gemm_s6.hip, 35.3 vs 33.1 us alone,
+            // tools/bench_linear.py -- at 2.5 GFLOP the launch is bound by its prologue and fill, not by the matrix pipe)
             if (!took)
                 AS_STEP("gru.xproj1", st, gemm_nt(l1_in, 2 * H, P + L.w_ih[1], 2 * H, ws + w.xp1, 6 * H, P + L.b_ih[1], R, 6 * H, 2 * H, 0, st));
         }
         AS_STEP("gru.fwd_l1", st, as_gru_bidir_fwd(ws + w.xp1, nullptr, 0, P + L.w_hh[1], P + L.b_hh[1], lengths, B, T, H, ws + w.y1,
                                 train ? ws + w.g1 : nullptr, st));
-        // (the trunk Linear and its input gradient stay on the general fp32-MFMA kernel: on the split-arithmetic kernel they
-        // were measured slower -- 15 vs 10 us, 14 vs 9 us -- 100-200 workgroups that each stream the whole weight from L2)
+        // (trunk Linear: 10.5 us on the fp32 instruction, 14 - 23 us on either split kernel: 50 - 200 short workgroups)
         AS_STEP("trunk.linear", st, gemm_nt(ws + w.y1, 2 * H, P + L.lin_w, 2 * H, ws + w.lin, H, P + L.lin_b, R, H, 2 * H, 1, st));
     } else if (pdrop > 0.f) {
         // SimpleArtSpeech in training mode (models.py:64,85): Dropout acts on the embedded frame, so every position has its

@@ -14,7 +14,10 @@ struct as_wgrad_job {
     float* colsum_b; long colsum_b_batch;
     int c_trans;
 };
-int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st);
+// exact: the fp32 matrix instruction whatever as_matrix_arith() says -- for launches that run BESIDE a latency-bound kernel: the
+// bf16 instruction draws more power, the chip clocks ~10 % lower under it, and a recurrence on the other CUs pays that on
+// every dependent step (measured in the BiGRU step: weight gradients 161 -> 114 us, the recurrence beside them 115 -> 131 us).
+int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st, bool exact = false);
 
 // How fp32 matrix products are formed (as_set_matrix_arith, include/artspeech_hip.h):
 //   AS_ARITH_FP32    v_mfma_f32_32x32x2_f32 on the fp32 operands (every kernel has this path)
@@ -33,6 +36,13 @@ struct as_planes_job {
 int as_emit_planes(const as_planes_job* jobs, int n, hipStream_t st);
 static inline long as_planes_batch_stride(int rows_pad, int Kpad) { return (long)(Kpad / 16) * rows_pad * 16; }
 static inline long as_planes_floats(int batch, int rows_pad, int Kpad) { return 3 * batch * as_planes_batch_stride(rows_pad, Kpad) / 2; }
+
+// gemm_s6.hip: C[g] = act(A[g][M][K] . B[g][N][K]^T + bias[g]) with both operands fp32 and reduction-contiguous, in the split
+// arithmetic (both split inside the kernel: no plane copies).  K % 16 == 0, lda / ldb / batch strides % 4 == 0, 16-byte aligned
+// operands.  1 = launched, 0 = not a case (mode fp32, shape, alignment: take as_gemm_f32), < 0 = error.
+int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long ldb, long b_batch, const float* bias, long bias_batch, float* C,
+                  long ldc, long c_batch, int M, int N, int K, int batch, int act, hipStream_t st);
+template <int N> struct IC2 { static constexpr int value = N; };
 
 // lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):
 //   C[bz] = epilogue(A[bz] [M][K] . B[bz]),  B[bz] = [N][K] (b_kc: forward) or [K][N] (backward); N <= 256, K % 32 == 0.

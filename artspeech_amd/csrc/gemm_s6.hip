@@ -1,0 +1,184 @@
+// General "NT" GEMM in the split matrix arithmetic (as_set_matrix_arith(1)):  C[g][M][N] = act(A[g][M][K] . B[g][N][K]^T + bias)
+// with BOTH operands fp32 in memory, reduction-contiguous (an nn.Linear forward: encoder_decoder/models.py:111-116 -- the GRU
+// input projection, the trunk Linear -- and, with a transposed copy of the weights, its input gradient).  Each fp32 operand
+// element is split exactly into three bfloat16 numbers and the product is rebuilt from six plane products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (lin_f32.hip has the arithmetic's rationale and its error measurements).
+//
+// Shape of the kernel -- what the measurements of lin_s6_kernel asked for:
+//   * that kernel's loop is bound by the bytes its CUs pull from L2 (a wave streams the weight planes of its own 32 columns:
+//     9.3 B per SIMD-cycle of matrix work at 64 x 256 tiles): here BOTH operands go through LDS, staged once per workgroup,
+//     on square 128 x 128 tiles -- 5.3 B per SIMD-cycle, and no pre-split copy of the weights (no plane-emit launch);
+//   * 4 waves (2 x 2), a wave owns 64 x 64 = four accumulators: a fragment read from LDS feeds two matrix instructions per
+//     plane pair (12 ds_read_b128 per 24 MFMAs and 16-deep k-step);
+//   * every thread loads 4 + 4 consecutive k of two A rows and two B rows per 16-deep k-tile (global_load_dwordx4, two tiles
+//     ahead in two register sets), splits them (4.5 vector instructions per element, each element once per workgroup) and
+//     writes 3 x 8 bytes per load into the tile's plane images ([plane][128 rows][16 k] bf16 = 32-byte rows, the two 16-byte
+//     halves XOR-swizzled by (row >> 3) & 1: the 16 lanes one LDS cycle of a ds_read_b128 serves then cover all 64 banks);
+//   * 48 KB of LDS (two tiles) and <= 168 VGPRs: three workgroups per CU, each other's split / barrier / epilogue phases under
+//     each other's matrix work; one barrier per k-tile.
+#include "gemm_internal.h"
+#include "split_arith.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TB = 128, BK = 16, NTH = 256;
+constexpr int PLANE = TB * BK * 2;        // bytes of one plane of one operand tile: 128 rows x 16 bf16
+constexpr int OPER = 3 * PLANE;           // one operand's three planes
+constexpr int BUF = 2 * OPER;             // A then B
+
+struct S6K {
+    const float* A; long lda, a_batch;
+    const float* B; long ldb, b_batch;
+    float* C; long ldc, c_batch;
+    const float* bias; long bias_batch;
+    int M, N, K, act, tiles_m, tiles_n;
+};
+
+typedef const __attribute__((address_space(1))) char* gptr;
+typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
+__device__ __forceinline__ gptr uniform_ptr(const void* p) {   // see lin_f32.hip
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<gptr>(((uintptr_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * BUF];
+    // block -> (batch, n-tile, m-tile): the m-tiles of one (batch, n-tile) are consecutive (they share the B panel in L2)
+    int t = blockIdx.x;
+    const int tm = t % g.tiles_m;
+    t /= g.tiles_m;
+    const int tn = t % g.tiles_n, bz = t / g.tiles_n;
+    const int m0 = tm * TB, n0 = tn * TB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // loads: thread -> rows (tid >> 2) and (tid >> 2) + 64 of each operand tile, 16-byte chunk tid & 3 of the row's 16 k
+    const int lrow = tid >> 2, lch = tid & 3;
+    const gptr Au = uniform_ptr(g.A + (long)bz * g.a_batch), Bu = uniform_ptr(g.B + (long)bz * g.b_batch);
+    unsigned a_off[2], b_off[2];
+    int wr[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = lrow + 64 * q;
+        a_off[q] = (unsigned)((long)min(m0 + r, g.M - 1) * g.lda + lch * 4) * 4u;    // bytes (operands < 4 GB: host check)
+        b_off[q] = (unsigned)((long)min(n0 + r, g.N - 1) * g.ldb + lch * 4) * 4u;
+        wr[q] = r * 32 + (((lch >> 1) ^ ((r >> 3) & 1)) * 16) + (lch & 1) * 8;
+    }
+    const int nk = g.K / BK;
+    struct Regs { f32x4 a[2], b[2]; };
+    auto load = [&](Regs& x, int kt) {
+        const unsigned ko = (unsigned)(min(kt, nk - 1) * BK) * 4u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            x.a[q] = *reinterpret_cast<gptr_f4>(Au + (a_off[q] + ko));
+            x.b[q] = *reinterpret_cast<gptr_f4>(Bu + (b_off[q] + ko));
+        }
+    };
+    auto store = [&](const Regs& x, int buf) {
+        unsigned char* base = sm + buf * BUF;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 v = o == 0 ? x.a[q] : x.b[q];
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split_pair(v.x, v.y, h0, m0_, l0);
+                split_pair(v.z, v.w, h1, m1, l1);
+                unsigned char* d = base + o * OPER + wr[q];
+                *reinterpret_cast<u32x2*>(d) = (u32x2){h0, h1};
+                *reinterpret_cast<u32x2*>(d + PLANE) = (u32x2){m0_, m1};
+                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = (u32x2){l0, l1};
+            }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fsw = ((l31 >> 3) & 1) ^ lh;     // 16-byte half of this lane's 8 k inside its (swizzled) row
+    const unsigned char* a_rd = sm + (wm * 64 + l31) * 32 + fsw * 16;
+    const unsigned char* b_rd = sm + OPER + (wn * 64 + l31) * 32 + fsw * 16;
+
+    Regs x[2];
+    load(x[0], 0);
+    load(x[1], 1);
+    store(x[0], 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // k-tile kt (U = kt & 1): images in buffer U; x[U ^ 1] holds tile kt + 1, x[U] is refilled with tile kt + 2
+    auto tile = [&](auto Uc, int kt) {
+        constexpr int U = decltype(Uc)::value;
+        load(x[U], kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i][p] = *reinterpret_cast<const bf16x8*>(a_rd + U * BUF + p * PLANE + i * 32 * 32);
+                fb[i][p] = *reinterpret_cast<const bf16x8*>(b_rd + U * BUF + p * PLANE + i * 32 * 32);
+            }
+        constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {0, 1, 2, 0, 1, 0};   // without mid.lo, lo.mid, lo.lo
+#pragma unroll
+        for (int o = 0; o < 6; ++o)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[j][PB[o]], acc[i][j], 0, 0, 0);
+        store(x[U ^ 1], U ^ 1);   // (behind the last tile: a clamped repeat into the idle buffer)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        tile(IC2<0>{}, kt);
+        tile(IC2<1>{}, kt + 1);
+    }
+    if (kt < nk) tile(IC2<0>{}, kt);
+
+    // ---- epilogue: D[i][j] block (i, j) of the wave: row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = n0 + wn * 64 + j * 32 + l31
+    float* C = g.C + (long)bz * g.c_batch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bj = g.bias ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bj;
+                    if (g.act == 1) v = as_relu(v);
+                    else if (g.act == 2) v = as_sigmoid(v);
+                    C[(long)row * g.ldc + col] = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+// see gemm_internal.h
+int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long ldb, long b_batch, const float* bias, long bias_batch, float* C,
+                  long ldc, long c_batch, int M, int N, int K, int batch, int act, hipStream_t st) {
+    if (as_matrix_arith() != AS_ARITH_BF16X6) return 0;
+    if (!A || !B || !C || M < 1 || N < 1 || K < BK || K % BK || batch < 1 || act < 0 || act > 2) return 0;
+    if (lda % 4 || ldb % 4 || a_batch % 4 || b_batch % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
+    if ((long)M * lda >= (1L << 30) || (long)N * ldb >= (1L << 30)) return 0;   // 32-bit byte offsets inside one batch member
+    S6K k{A, lda, a_batch, B, ldb, b_batch, C, ldc, c_batch, bias, bias_batch, M, N, K, act, as_cdiv(M, TB), as_cdiv(N, TB)};
+    const long blocks = (long)k.tiles_m * k.tiles_n * batch;
+    if (blocks > (1L << 30)) return 0;
+    hipLaunchKernelGGL(gemm_s6_nt_kernel, dim3((unsigned)blocks), dim3(NTH), 0, st, k);
+    AS_LAUNCH_CHECK("as_gemm_s6_nt");
+    return 1;
+}

@@ -1459,6 +1459,11 @@ extern "C" int as_linear_fwd(const float* A, int64_t lda, const float* W, int64_
                "as_linear_fwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     int bn, nb;
+    if (!planes_ws) {   // both operands split inside the kernel (gemm_s6.hip): no scratch needed
+        const int took = as_gemm_s6_nt(A, lda, 0, W, ldw, 0, bias, 0, out, ldo, 0, M, N, K, 1, act, st);
+        AS_REQUIRE(took >= 0, took, "as_linear_fwd: launch failed");
+        if (took) return 0;
+    }
     if (as_matrix_arith() == AS_ARITH_BF16X6 && planes_ws && K % S6_BK == 0 && lda % 4 == 0 && linear_blocks(N, &bn, &nb) &&
         (reinterpret_cast<uintptr_t>(planes_ws) & 15) == 0) {
         const int rows_last = N - (nb - 1) * bn;   // (nb > 1: whole blocks)

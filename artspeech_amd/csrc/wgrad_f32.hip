@@ -571,9 +571,9 @@ bool describe(const as_gemm* g, WgradK& k) {
 }
 
 template <int BNT>
-int launch_multi(WgradMulti& mm, int bk, hipStream_t st) {
+int launch_multi(WgradMulti& mm, int bk, hipStream_t st, bool exact = false) {
     const dim3 grid((unsigned)(8 * mm.per_xcd));
-    const bool s6 = as_matrix_arith() == AS_ARITH_BF16X6 && bk == 32;
+    const bool s6 = !exact && as_matrix_arith() == AS_ARITH_BF16X6 && bk == 32;
     if (mm.streamk && s6) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true, true>), grid, dim3(NT), 0, st, mm);
     else if (mm.streamk) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 32, true>), grid, dim3(NT), 0, st, mm);
     else if (bk == 16) hipLaunchKernelGGL((wgrad_f32_kernel<BNT, 16>), grid, dim3(NT), 0, st, mm);
@@ -681,7 +681,7 @@ int as_wgrad_try(const as_gemm* g, hipStream_t st) {
 // grid is a few rounds of the CUs the caller expects (cu_budget, 0 = chip): many short workgroups instead of one long one
 // per CU, so the dispatcher fills every free CU and other streams' kernels get CUs as workgroups retire.
 // 1 = launched, 0 = not a case (nothing launched: the caller issues the problems one by one), < 0 = error.
-int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st) {
+int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_floats, int cu_budget, hipStream_t st, bool exact) {
     static const bool off = AS_DIAG_SET("AS_NO_WGRAD_MULTI");  // ablation: one launch per problem
     if (off || n < 1 || n > MAXP || !slab) return 0;
     WgradMulti mm{};
@@ -736,6 +736,6 @@ int as_wgrad_multi(const as_wgrad_job* jobs, int n, float* slab, long slab_float
     mm.total_items = item0;
     mm.total_red = red0;
     mm.per_xcd = (int)((item0 + 7) / 8);
-    const int rc = launch_multi<256>(mm, 32, st);
+    const int rc = launch_multi<256>(mm, 32, st, exact);
     return rc == 0 ? 1 : rc;
 }

@@ -267,7 +267,9 @@ int as_gemm_f32(const as_gemm* g, void* stream);
  * encoder_decoder/models.py:12-16, 113-116 and transformer/models.py:47-60), in the library's current matrix arithmetic
  * (as_set_matrix_arith): mode 1 emits W as three bfloat16 planes into `planes_ws` (>= as_linear_planes_floats(N, K) floats of
  * scratch, 16-byte aligned) and multiplies on v_mfma_f32_32x32x16_bf16 where the shape allows (K % 32 == 0; N <= 256 or
- * N % 256 == 0; lda % 4 == 0); everything else -- and mode 0 -- runs as_gemm_f32.  tests/ hold both modes' error against an fp64
+ * N % 256 == 0; lda % 4 == 0); planes_ws == NULL: both operands are split inside the kernel instead (128 x 128 tiles, K % 16
+ * == 0, lda % 4 == 0, ldw % 4 == 0: the form the GRU input projection and the trunk Linear use); everything else -- and mode 0
+ * -- runs as_gemm_f32.  tests/ hold both modes' error against an fp64
  * product of the same operands. */
 int64_t as_linear_planes_floats(int32_t N, int32_t K);
 int as_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
