@@ -109,6 +109,7 @@ PROTOTYPES = {
     "as_relu_bwd": (_I32, [_P, _P, _P, _I64, _P]),
     "as_add": (_I32, [_P, _P, _P, _I64, _P]),
     "as_row_scale": (_I32, [_P, _P, _P, _I64, _I32, _P]),
+    "as_copy_f32": (_I32, [_P, _P, _I64, _P]),
     "as_set_overlap": (None, [_I32]),
     "as_set_matrix_arith": (None, [_I32]),
     "as_get_matrix_arith": (_I32, []),

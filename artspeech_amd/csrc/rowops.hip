@@ -4,6 +4,8 @@
 // LayerNorm affine parameters, per-token segment sums (embedding / layer-0 input-projection
 // gradients), gather, sigmoid backward and the flat Adam update.  All HBM-bound: one wave per row,
 // coalesced 4-byte or 16-byte lanes, wave shuffles for the row reductions.
+#include <algorithm>
+
 #include "gemm_internal.h"
 #include "rowops.h"
 
@@ -1245,5 +1247,24 @@ extern "C" int as_adam_step(float* params, const float* grads, float* exp_avg, f
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
     AS_LAUNCH_CHECK("as_adam_step");
+    return 0;
+}
+
+// ---- streaming copy probe (bench.py: the box's measured HBM copy rate, the denominator beside the 8 TB/s specification):
+// float4 grid-stride loop, 16 B per lane per access, non-temporal loads and stores are left to the cache policy's default.
+namespace {
+__global__ __launch_bounds__(256) void copy_f32x4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+}  // namespace
+extern "C" int as_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
+    AS_REQUIRE(src && dst && n > 0 && n % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+               AS_ERR_BAD_ARG, "as_copy_f32: n %% 4 == 0, 16-byte aligned buffers");
+    const long n4 = n / 4;
+    const long blocks = std::min<long>((n4 + 255) / 256, 256L * 32);   // 32 workgroups per CU, each lane ~n4 / 2 M accesses
+    hipLaunchKernelGGL(copy_f32x4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), n4);
+    AS_LAUNCH_CHECK("as_copy_f32");
     return 0;
 }

@@ -114,7 +114,9 @@ class TrainStep:
         lo, n = self.late_off, self.grads.numel() - self.late_off
         if self.use_dist:
             with torch.cuda.stream(stream):
+                ev = self._ar_mark("late", stream)
                 torch.distributed.all_reduce(self.grads[lo:], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._ar_mark_end(ev, stream)
         _lib.check(L.as_adam_step(_lib.ptr(P[lo:]), _lib.ptr(self.grads[lo:]), _lib.ptr(self.exp_avg[lo:]),
                                   _lib.ptr(self.exp_avg_sq[lo:]), n, self.lr, self.betas[0], self.betas[1], self.eps,
                                   self.weight_decay, self.pending, 1.0, sp), "as_adam_step")
@@ -152,12 +154,47 @@ class TrainStep:
             dist.all_reduce(self.grads[:end], op=dist.ReduceOp.SUM, group=self.pg)
             return
         _lib.check(_lib.lib().as_artspeech_wait_head_grads(_lib.stream_ptr(), self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
+        cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.comm_stream):
+            ev_t = self._ar_mark("tail", self.comm_stream)
             tail = dist.all_reduce(self.grads[self.head_off:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if ev_t is not None:   # timing pass: the piece's end on its own stream
+                tail.wait()
+                self._ar_mark_end(ev_t, self.comm_stream)
+        ev_x = self._ar_mark("exposed", cur)    # from here on the compute stream does nothing but communicate / wait
+        ev_h = self._ar_mark("head", cur)
         head = dist.all_reduce(self.grads[:self.head_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        tail.wait()
         head.wait()
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._ar_mark_end(ev_h, cur)
+        tail.wait()
+        cur.wait_stream(self.comm_stream)
+        self._ar_mark_end(ev_x, cur)
+
+    # ---- optional timing of the gradient exchange (bench.py --gpus N): stream events around each of its pieces -- "tail"
+    # (trunk + heads, on the communication stream beside the GRU backward), "head" (GRU + embedding, on the compute stream
+    # after the backward), "late" (the deferred slice, on the late stream in the next step's forward) -- and "exposed": the
+    # span of the compute stream between the end of the backward and the start of Adam, i.e. what the exchange costs the step.
+    ar_timing = False
+
+    def _ar_mark(self, name, stream):
+        if not self.ar_timing:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        return (name, e0, e1)
+
+    def _ar_mark_end(self, ev, stream):
+        if ev is not None:
+            ev[2].record(stream)
+            self.__dict__.setdefault("_ar_events", []).append(ev)
+
+    def ar_report(self):
+        """{piece: mean milliseconds} over the steps run with ``ar_timing`` on (synchronises); clears the record."""
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in self.__dict__.pop("_ar_events", []):
+            acc.setdefault(name, []).append(e0.elapsed_time(e1))
+        return {k: round(sum(v) / len(v), 4) for k, v in acc.items()}
 
     def adam(self):
         L = _lib.lib()

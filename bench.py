@@ -44,7 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 V, A, E, H, N = 45, 11, 64, 128, 50
 B, T = 32, 200
 D = 256                      # width of the ArticulatorPredictor hidden layers
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s specification (this box's own copy rate: roofline.peak_measured_copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # compulsory HBM bytes of one BiGRU fwd+bwd step at B=32, T=200 = 30.3 KB / frame
 STEP_BYTES_PER_FRAME = 30.3e3
@@ -71,9 +71,9 @@ def gemm_flops(rows):
 # GEMM phases grouped by the kernels that run them, named as rocprofv3 prints them (profiles/r02_kernel_stats.csv).
 # head.gemm1/2 and headb.dx3/2 are the fused Linear + LayerNorm kernels: their time includes the LayerNorm epilogue.
 GEMM_FAMILIES = {
-    "forward (C = act(A.B^T + b)): lin_f32_kernel<64, true, 1> [head Linear 1, 2 + ReLU + LayerNorm] + lin_out_kernel [output layer; its time includes the fused criterion epilogue] + gemm_f32_kernel<*, *, true, true, true>":
+    "forward (C = act(A.B^T + b)): lin_s6_kernel<1> | lin_f32_kernel<64, true, 1> [head Linear 1, 2 + ReLU + LayerNorm] + lin_out_s6_kernel | lin_out_kernel [output layer; its time includes the fused criterion epilogue] + gemm_f32_kernel<*, *, true, true, true>":
         ["gru.table0", "gru.xproj1", "trunk.linear", "head.gemm1", "head.gemm2", "head.gemm3"],
-    "input gradients (C = A.B): lin_f32_kernel<64, false, 2> [head dx 3, 2 + LayerNorm/ReLU backward] + gemm_f32_kernel<*, *, true, false, true>":
+    "input gradients (C = A.B): lin_s6_kernel<2> | lin_f32_kernel<64, false, 2> [head dx 3, 2 + LayerNorm/ReLU backward] + lin_s6_plain_kernel<4> [heads dx1, split K] + gemm_f32_kernel<*, *, true, false, true>":
         ["headb.dx3", "headb.dx2", "headb.dx1", "trunkb.dx", "grub.dx1", "grub.demb"],
     "weight gradients (C = A^T.B): wgrad_f32_kernel<256, 32>(WgradMulti) [heads + trunk: two multi-problem launches, one of them a step late] + gemm_f32_kernel<64, 64, false, false, true> [GRU]":
         ["headb.dw_fused", "headb.dw31", "headb.dw3", "headb.dw2", "headb.dw1", "trunkb.dw", "grub.dw_ih1", "grub.dw_hh", "grub.dw_ih0"],
@@ -99,7 +99,7 @@ GRU_BWD_TOK_KERNEL = "gru_bwd_row_kernel<128, true, 2>"
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
     runs, gfx950 correction applied: tools/collect_profiles.py), newest round first, or None."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if not os.path.exists(path):
             continue
@@ -111,6 +111,19 @@ def pmc_traffic(kernel):
     return None
 
 
+def pmc_step_traffic():
+    """Whole-step HBM bytes (every kernel of this library, launches per step x PMC bytes per launch) from the newest committed
+    rocprofv3 --pmc passes, or None: tools/collect_profiles.py writes `_step_traffic_bytes`."""
+    for tag in ("r04",):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                table = json.load(f)
+            if "_step_traffic_bytes" in table:
+                return int(table["_step_traffic_bytes"]), f"profiles/{tag}_pmc_traffic.json"
+    return None, None
+
+
 def measured_copy_gbs(dev, mib=1024, reps=64):
     """Streaming copy rate of THIS box (read + write bytes over time, a 1 GiB fp32 tensor copied `reps` times; the rate of
     the LAST quarter of the copies counts): the measured denominator SURVEY 8(d) asks for beside the 8 TB/s spec figure.
@@ -119,16 +132,21 @@ def measured_copy_gbs(dev, mib=1024, reps=64):
     this benchmark falls smoothly from 1.23 to 1.10 ms over the first 20 steps of a process,
     profiles/r03_step_warmup_curve.txt), hence 64 copies with the last 16 counted.
     Returns (GB/s, milliseconds the probe kept the GPU busy)."""
+    from artspeech_amd import _lib
+    L = _lib.lib()
     src = torch.empty(mib << 18, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
+
+    def copy():   # the library's float4 grid-stride kernel (torch's copy_ reads 10-25 % lower on this box)
+        _lib.check(L.as_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), _lib.stream_ptr()), "as_copy_f32")
+    copy()
     tail = max(1, reps // 4)
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
     for i in range(reps):
         if i == reps - tail:
             e1.record()
-        dst.copy_(src)
+        copy()
     e2.record()
     torch.cuda.synchronize()
     return round(2.0 * src.numel() * 4 * tail / (e1.elapsed_time(e2) * 1e-3) / 1e9, 1), round(e0.elapsed_time(e2), 2)
@@ -229,6 +247,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] measurements (N = 1)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the second run on the exact fp32 matrix instruction (N = 1)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -330,6 +349,32 @@ def main():
             del st, inp
     head = runs[args.scaling]
     ms_per_step = head["ms_per_step"]
+    # N > 1: what the gradient exchange costs each rank, piece by piece (stream events, every rank runs the same steps)
+    exchange = None
+    if world > 1:
+        st_, (tok_, len_, tgt_, sc_) = head_step, head_inputs
+        st_.flush()
+        st_.ar_timing = True
+        for _ in range(min(args.steps, 10)):
+            st_.step(tok_, len_, tgt_, sc_)
+        st_.flush()
+        st_.ar_timing = False
+        mine = {"rank": rank, "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0, "ms": st_.ar_report()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        exchange = {"note": "mean ms per step of each piece of the flat-gradient all-reduce on its own stream (tail: trunk + heads, beside "
+                            "the GRU backward; head: GRU + embedding, after the backward; late: the deferred slice, in the next step's "
+                            "forward) and `exposed`: the span of the compute stream between backward and Adam", "by_rank": gathered}
+    # the same run on the exact fp32 matrix instruction everywhere (as_set_matrix_arith(0)): the headline's arithmetic is the
+    # split one (fp32 operands as three bfloat16 planes, six plane products, fp32 accumulation) in the kernels that have it
+    L_ = _lib.lib()
+    arith_mode = int(L_.as_get_matrix_arith())
+    exact_run = None
+    if arith_mode != 0 and world == 1 and not args.no_exact:
+        L_.as_set_matrix_arith(0)
+        exact_run, st_, inp_ = measure(args.scaling, args.per_gpu_batch)
+        del st_, inp_
+        L_.as_set_matrix_arith(arith_mode)
 
     # ---- instrumented pass (rank 0): per-kernel-phase HIP events on each phase's own launch stream ----------------
     roofline, kernels = None, None
@@ -407,6 +452,11 @@ def main():
         step_gbs = STEP_BYTES_PER_FRAME * rows / (ms_per_step * 1e-3) / 1e9
         roofline["step_hbm"] = {"algorithmic_bytes_per_step": STEP_BYTES_PER_FRAME * rows, "achieved_GBs": round(step_gbs, 1),
                                 "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 5)}
+        # what the step REALLY moves through HBM (PMC counters of every kernel, committed profile) against the compulsory bytes
+        st_bytes, st_src = pmc_step_traffic()
+        roofline["step_traffic_bytes"] = st_bytes
+        roofline["step_traffic_over_compulsory"] = round(st_bytes / (STEP_BYTES_PER_FRAME * B * T), 2) if st_bytes else None
+        roofline["step_traffic_source"] = st_src
     del head_step, head_inputs
 
     if rank == 0:
@@ -464,11 +514,21 @@ def main():
                                    "next step's forward recurrences; flushed inside the timed region)"),
                        "global_batch": head["global_batch"], "seq_len": T, "parallelism": f"dp{world}"},
             "loss": head["loss"],
+            # fp32 in, fp32 out, fp32 accumulation everywhere; how the PRODUCTS of the matrix kernels are formed:
+            "arith": ("bf16x6: every fp32 operand split exactly into three bfloat16 numbers, six of the nine plane products on "
+                      "v_mfma_f32_32x32x16_bf16, fp32 accumulate -- in the fused head layers (Linear + LayerNorm forward and backward), "
+                      "the output layer and the heads' input gradient; v_mfma_f32_32x32x2_f32 (exact fp32) in the GRU-side GEMMs and in "
+                      "the weight gradients that run beside the recurrences; error against fp64 <= the fp32 instruction's "
+                      "(tests/test_gpu_parity.py::test_split_matrix_arithmetic_*)") if arith_mode else "fp32: v_mfma_f32_32x32x2_f32 everywhere",
+            "exact_fp32": ({"ms_per_step": exact_run["ms_per_step"], "value": exact_run["value"], "loss": exact_run["loss"],
+                            "note": "same command, as_set_matrix_arith(0): every matrix kernel on v_mfma_f32_32x32x2_f32"}
+                           if exact_run else None),
             # ranks that exchanged gradients over RCCL (0 in a gloo rehearsal, where no RCCL communicator exists)
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "rehearsal_shared_gpu": bool(world > 1 and backend != "nccl"),
             "scaling_runs": runs,
+            "gradient_exchange": exchange,
             "roofline": roofline,
             "kernels_us_per_step": kernels,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(state_dict),  # rank 0 at N = 1 only

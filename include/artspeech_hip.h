@@ -140,6 +140,10 @@ int as_artspeech_dw2(const as_dims* dims, const float* params, int32_t B, int32_
  * capturing).  as_set_overlap(0) keeps every kernel on `stream` (default on; env ARTSPEECH_NO_OVERLAP=1 = off). */
 void as_set_overlap(int32_t on);
 
+/* Streaming copy dst[i] = src[i] of n floats (n % 4 == 0, 16-byte aligned): a float4 grid-stride kernel.  bench.py times it on
+ * 1 GiB to quote the box's measured HBM copy rate (read + write bytes over time) beside the 8 TB/s specification. */
+int as_copy_f32(const float* src, float* dst, int64_t n, void* stream);
+
 /* How the library forms fp32 matrix products (every nn.Linear / weight gradient of the path; the reference computes them
  * in fp32: encoder_decoder/models.py:10-33, transformer/models.py:37-100):
  *   0  v_mfma_f32_32x32x2_f32 on the fp32 operands (the exact fp32 matrix instruction);

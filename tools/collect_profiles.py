@@ -27,11 +27,16 @@ def newest(pattern):  # gpurun_out/ accumulates the outputs of earlier calls: ta
 shutil.copy(newest(os.path.join(stats_dir, "*", "*_kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 
+COUNTS = {}   # kernel -> dispatches seen in the FETCH_SIZE pass
+
+
 def per_kernel(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    if counter == "FETCH_SIZE":
+        COUNTS.update({k: len(v) for k, v in acc.items()})
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -43,6 +48,17 @@ for k in sorted(set(fetch) | set(write)):
     if "anonymous namespace" not in k:
         continue  # only this library's kernels
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    res[k] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes_per_launch": int(1024 * (2 * f + w))}
+    res[k] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes_per_launch": int(1024 * (2 * f + w)),
+              "dispatches": COUNTS.get(k, 0)}
+# whole training step: the forward recurrence kernel runs exactly twice per step (layer 0, layer 1) -> steps in the pass
+n_fwd = sum(c for k, c in COUNTS.items() if "gru_fwd_kernel" in k)
+if n_fwd >= 2:
+    steps = n_fwd / 2
+    total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in res.items() if isinstance(v, dict))
+    res["_steps_in_pass"] = steps
+    res["_step_traffic_bytes"] = int(total / steps)
+    for k, v in res.items():
+        if isinstance(v, dict):
+            v["launches_per_step"] = round(v["dispatches"] / steps, 2)
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k[:70]: v for k, v in res.items() if "gru" in k}, indent=1))
