@@ -1355,7 +1355,8 @@ int as_lin_try(const as_lin* a, hipStream_t st) {
 
 // see gemm_internal.h
 int as_lin_plain_s6(const as_lin* a, int ksplit, long c_split, hipStream_t st) {
-    if (as_matrix_arith() != AS_ARITH_BF16X6 || !a->Bp) return 0;
+    static const bool off = AS_DIAG_SET("AS_NO_PLAIN_S6");   // diagnostic: callers fall back to the general fp32 kernel
+    if (off || as_matrix_arith() != AS_ARITH_BF16X6 || !a->Bp) return 0;
     if (a->epi != EPI_PLAIN || a->K % S6_BK || a->K < S6_BK || a->N > BN || a->N < 1 || a->M < 1 || a->batch < 1 || !a->C) return 0;
     if (!aligned16(a->A) || a->lda % 4 || a->a_batch % 4 || a->lda >= (1L << 23)) return 0;
     if ((reinterpret_cast<uintptr_t>(a->Bp) & 15) || a->bp_plane % 8 || a->bp_batch % 8) return 0;
@@ -1423,7 +1424,8 @@ int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st) {
     const long total = (long)k.n_big + (long)k.small_per_batch * k.batch;
     if (k.small_per_batch == 0) k.small_per_batch = 1;
     if (k.tgt && total > a->partial_capacity) return 0;
-    if (a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= ON && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
+    static const bool no_s6 = AS_DIAG_SET("AS_NO_LIN_OUT_S6");   // diagnostic: the output layer on the fp32 instruction
+    if (!no_s6 && a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= ON && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
         a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0 && a->lda < (1L << 23)) {
         k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
         hipLaunchKernelGGL(lin_out_s6_kernel, dim3((unsigned)total), dim3(256), 0, st, k);
