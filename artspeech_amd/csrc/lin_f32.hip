@@ -1150,48 +1150,46 @@ __global__ __launch_bounds__(256, 4) void lin_out_s6_kernel(LinOutK g) {
     const int Np = g.N >> 1;                                    // points per contour
     float part = 0.f;
     if (Np <= 64) {
-        // one wave per frame at a time, lanes over the points, 8 frames per pass with ALL their target coordinates requested
-        // before the first store goes out (see lin_out_kernel)
+        // one wave per frame at a time, lanes over the points; ALL target coordinates of the wave's 16 frames are requested
+        // before the first store goes out (vector memory operations retire in order: a load issued behind a frame's stores
+        // waits for their acknowledgement -- two passes of 8 frames cost the second pass exactly that, see lin_out_kernel)
         const int nl = min(lane, Np - 1);
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            float tx[8], ty[8];
-            bool in[8], valid[8];
+        float tx[16], ty[16];
+        bool in[16], valid[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = wave_u + 4 * (8 * pass + k);
-                const int frame = m0 + r;
-                in[k] = r < rows && frame < g.M;
-                const int fc = in[k] ? frame : m0;
-                const int b = fc / g.T, t = fc - b * g.T;
-                valid[k] = in[k] && t < g.lengths[b];
-                const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
-                tx[k] = tg[nl];
-                ty[k] = tg[Np + nl];
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int r = wave_u + 4 * k;
+            const int frame = m0 + r;
+            in[k] = r < rows && frame < g.M;
+            const int fc = in[k] ? frame : m0;
+            const int b = fc / g.T, t = fc - b * g.T;
+            valid[k] = in[k] && t < g.lengths[b];
+            const float* tg = g.tgt + (((long)b * g.tgt_T + t) * g.batch + bz) * g.N;
+            tx[k] = tg[nl];
+            ty[k] = tg[Np + nl];
+        }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (!in[k]) continue;                       // wave-uniform
-                const int r = wave_u + 4 * (8 * pass + k);
-                const long frame = m0 + r;
-                float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
-                float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
-                if (lane < Np) {
-                    const float ox = smem[r * ON + lane], oy = smem[r * ON + Np + lane];
-                    o[lane] = ox;
-                    o[Np + lane] = oy;
-                    float gx = 0.f, gy = 0.f;
-                    if (valid[k]) {
-                        const float dx = ox - tx[k], dy = oy - ty[k];
-                        const float d = sqrtf(dx * dx + dy * dy);
-                        part += d;
-                        const float gg = g.scale / d;                   // NaN at zero distance, as torch autograd
-                        gx = dx * gg * ox * (1.f - ox);                  // through the sigmoid (same product order as the unfused kernels)
-                        gy = dy * gg * oy * (1.f - oy);
-                    }
-                    dz[lane] = gx;
-                    dz[Np + lane] = gy;
+        for (int k = 0; k < 16; ++k) {
+            if (!in[k]) continue;                       // wave-uniform
+            const int r = wave_u + 4 * k;
+            const long frame = m0 + r;
+            float* o = g.out + frame * g.ldo + (long)bz * g.o_batch;
+            float* dz = g.dout + frame * g.ldo + (long)bz * g.o_batch;
+            if (lane < Np) {
+                const float ox = smem[r * ON + lane], oy = smem[r * ON + Np + lane];
+                o[lane] = ox;
+                o[Np + lane] = oy;
+                float gx = 0.f, gy = 0.f;
+                if (valid[k]) {
+                    const float dx = ox - tx[k], dy = oy - ty[k];
+                    const float d = sqrtf(dx * dx + dy * dy);
+                    part += d;
+                    const float gg = g.scale / d;                   // NaN at zero distance, as torch autograd
+                    gx = dx * gg * ox * (1.f - ox);                  // through the sigmoid (same product order as the unfused kernels)
+                    gy = dy * gg * oy * (1.f - oy);
                 }
+                dz[lane] = gx;
+                dz[Np + lane] = gy;
             }
         }
     } else
