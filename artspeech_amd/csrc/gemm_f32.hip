@@ -789,6 +789,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     AS_REQUIRE((g->b_j == 1) != (g->b_k == 1) || (g->b_j == 1 && g->b_k == 1 && (g->N == 1 || g->K == 1)),
                AS_ERR_BAD_ARG, "as_gemm_f32: exactly one of b_j/b_k must be 1 (b_j=%ld b_k=%ld)", (long)g->b_j, (long)g->b_k);
     AS_REQUIRE(g->act >= 0 && g->act <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: act=%d", g->act);
+    AS_REQUIRE(g->precision >= 0 && g->precision <= 3, AS_ERR_BAD_ARG, "as_gemm_f32: precision=%d", g->precision);
+    const int prec = g->precision == 3 ? 0 : g->precision;   // 3 = "the library's matrix arithmetic, at any size" (below)
     // (M == 1 with both strides of A equal to 1 reads the same either way: output-contiguous then, the form the column sums take)
     const bool a_kc = g->a_k == 1 && !(g->a_i == 1 && g->colsum), b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
@@ -815,7 +817,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.k_seg = g->k_seg; k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
     k.k_tri = g->k_tri;
     AS_REQUIRE(g->k_tri >= 0 && g->k_tri <= 2, AS_ERR_BAD_ARG, "as_gemm_f32: k_tri=%d", g->k_tri);
-    AS_REQUIRE(g->k_tri == 0 || (!g->colsum && !g->splitk_ws && g->precision == 0 && g->k_seg == 0 && !g->accumulate && g->act <= 1 &&
+    AS_REQUIRE(g->k_tri == 0 || (!g->colsum && !g->splitk_ws && prec == 0 && g->k_seg == 0 && !g->accumulate && g->act <= 1 &&
                                  !g->bias_off && (long)g->M * g->ldc < (1L << 31)),
                AS_ERR_BAD_ARG, "as_gemm_f32: k_tri goes with the extended general kernel only (no colsum, splitk_ws, split precision, "
                "k_seg, accumulate, act > 1)");
@@ -825,7 +827,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
                            (a_kc || !b_kc)))
         k.k_tri = 0;
     const bool epi_ops = g->res || g->mask_bits || g->relu_bits, segmented = g->k_seg > 0;
-    AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && g->precision == 0 && (a_kc || b_kc)),
+    AS_REQUIRE(!(epi_ops || segmented) || (!g->colsum && !g->splitk_ws && !g->accumulate && prec == 0 && (a_kc || b_kc)),
                AS_ERR_BAD_ARG, "as_gemm_f32: res / mask_bits / relu_bits / k_seg go with the general kernel only (no colsum, splitk_ws, "
                "accumulate, split precision or weight-gradient shape)");
     AS_REQUIRE(!g->relu_bits || g->act == 1, AS_ERR_BAD_ARG, "as_gemm_f32: relu_bits is the bit image of a ReLU epilogue (act == 1)");
@@ -844,11 +846,20 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
         k.b_vec = aligned16(g->B) && b_ld % 4 == 0;
     }
     AS_REQUIRE(!(g->colsum && a_kc), AS_ERR_BAD_ARG, "as_gemm_f32: colsum needs an output-contiguous A operand (a_i == 1)");
+    // precision == 3: the library's split matrix arithmetic (as_set_matrix_arith(1)) for forward shapes -- both operands
+    // reduction-contiguous, plain or ReLU-bit epilogue, linear or grouped batches -- on the bf16 matrix instruction with both
+    // operands split inside the kernel (gemm_s6.hip: 1.36 x this kernel on the transformer's block groups, 110 x [6400 x 256 x
+    // 256]).  Opt-in per call and independent of the launch's size: a size threshold would make the last bits of a result
+    // depend on the batch it was computed in (measured: 7e-5 on the transformer's contours between batches of 4 and 32).
+    if (a_kc && b_kc && g->precision == 3) {
+        const int took = as_gemm_s6_nt_ext(g, st);
+        if (took != 0) return took < 0 ? took : 0;
+    }
     // split-precision request (forward linears only): both operands reduction-contiguous and float4-clean, else exact fp32
-    if (g->precision != 0 && a_kc && b_kc && k.a_vec && k.b_vec && g->K % 4 == 0 && !g->colsum) {
+    if (prec != 0 && a_kc && b_kc && k.a_vec && k.b_vec && g->K % 4 == 0 && !g->colsum) {
         AS_REQUIRE(g->precision == 1 || g->precision == 2, AS_ERR_BAD_ARG, "as_gemm_f32: precision=%d", g->precision);
         const long work = (long)as_cdiv(g->M, 128) * as_cdiv(g->N, 128) * g->batch;
-        if (g->precision == 2) {
+        if (prec == 2) {
             static const int slots = resident_blocks(gemm_split_nt_kernel<128, 128, 3>);
             hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, 3>), dim3((unsigned)(work < slots ? work : slots)), dim3(256), 0, st, k);
         } else {

@@ -42,6 +42,9 @@ static inline long as_planes_floats(int batch, int rows_pad, int Kpad) { return 
 // operands.  1 = launched, 0 = not a case (mode fp32, shape, alignment: take as_gemm_f32), < 0 = error.
 int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long ldb, long b_batch, const float* bias, long bias_batch, float* C,
                   long ldc, long c_batch, int M, int N, int K, int batch, int act, hipStream_t st);
+// the same from an as_gemm descriptor: forward shapes (a_k == b_k == 1) incl. grouped offsets (a_off ...) and relu_bits; everything
+// else the descriptor may ask for (res, mask_bits, k_seg, k_tri, colsum, split K, accumulate, shifts) -> 0
+int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st);
 template <int N> struct IC2 { static constexpr int value = N; };
 
 // lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):

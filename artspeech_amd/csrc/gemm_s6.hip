@@ -36,6 +36,10 @@ struct S6K {
     float* C; long ldc, c_batch;
     const float* bias; long bias_batch;
     int M, N, K, act, tiles_m, tiles_n;
+    // grouped batches (as_gemm.a_off ...: element offsets per batch member instead of the linear strides) and the bit image of
+    // a ReLU epilogue (as_gemm.relu_bits: [batch][M][ceil(N / 32)] words, bit n % 32 of word n / 32 = result > 0)
+    const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
+    unsigned* relu_bits; long relu_bits_batch; int ncb;
 };
 
 typedef const __attribute__((address_space(1))) char* gptr;
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
     const int wm = wave >> 1, wn = wave & 1;
     // loads: thread -> rows (tid >> 2) and (tid >> 2) + 64 of each operand tile, 16-byte chunk tid & 3 of the row's 16 k
     const int lrow = tid >> 2, lch = tid & 3;
-    const gptr Au = uniform_ptr(g.A + (long)bz * g.a_batch), Bu = uniform_ptr(g.B + (long)bz * g.b_batch);
+    const gptr Au = uniform_ptr(g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch));
+    const gptr Bu = uniform_ptr(g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch));
     unsigned a_off[2], b_off[2];
     int wr[2];
 #pragma unroll
@@ -145,40 +150,92 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
     if (kt < nk) tile(IC2<0>{}, kt);
 
     // ---- epilogue: D[i][j] block (i, j) of the wave: row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = n0 + wn * 64 + j * 32 + l31
-    float* C = g.C + (long)bz * g.c_batch;
+    float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
+    const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
+    if (g.relu_bits == nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M) {
+                        float v = acc[i][j][r] + bj;
+                        if (g.act == 1) v = as_relu(v);
+                        else if (g.act == 2) v = as_sigmoid(v);
+                        C[(long)row * g.ldc + col] = v;
+                    }
+                }
+        }
+        return;
+    }
+    // ReLU epilogue that leaves its bit image (the backward's mask): a ballot per accumulator register holds the 32 columns of
+    // two rows; the 32 row words of a block are gathered into one register (v_writelane_b32, lane = block row) and stored by
+    // lanes 0..31.  (Two wait states between the compare and v_writelane_b32: hipcc does not look into inline assembly.)
+    unsigned* bits = g.relu_bits + (long)bz * g.relu_bits_batch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= g.N) continue;
-        const float bj = g.bias ? g.bias[(long)bz * g.bias_batch + col] : 0.f;
+        const bool cok = col < g.N;
+        const float bj = (bias && cok) ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bj;
-                    if (g.act == 1) v = as_relu(v);
-                    else if (g.act == 2) v = as_sigmoid(v);
-                    C[(long)row * g.ldc + col] = v;
-                }
+        for (int i = 0; i < 2; ++i) {
+            unsigned mine = 0;
+            const int rb = m0 + wm * 64 + i * 32;
+#define AS_S6_BITS(r)                                                                                                          \
+            {                                                                                                                 \
+                const float v = as_relu(acc[i][j][r] + bj);                                                                   \
+                const unsigned long long b = __ballot(cok && v > 0.f);                                                        \
+                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mine) : "s"((unsigned)b), "i"(((r) & 3) + 8 * ((r) >> 2))); \
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine) : "s"((unsigned)(b >> 32)), "i"(((r) & 3) + 8 * ((r) >> 2) + 4)); \
+                const int row = rb + ((r) & 3) + 8 * ((r) >> 2) + 4 * lh;                                                     \
+                if (cok && row < g.M) C[(long)row * g.ldc + col] = v;                                                         \
             }
+            AS_S6_BITS(0) AS_S6_BITS(1) AS_S6_BITS(2) AS_S6_BITS(3) AS_S6_BITS(4) AS_S6_BITS(5) AS_S6_BITS(6) AS_S6_BITS(7)
+            AS_S6_BITS(8) AS_S6_BITS(9) AS_S6_BITS(10) AS_S6_BITS(11) AS_S6_BITS(12) AS_S6_BITS(13) AS_S6_BITS(14) AS_S6_BITS(15)
+#undef AS_S6_BITS
+            const int word = (n0 + wn * 64 + j * 32) >> 5;
+            if (lane < 32 && rb + lane < g.M && word < g.ncb) bits[(long)(rb + lane) * g.ncb + word] = mine;
+        }
     }
 }
 
 }  // namespace
 
 // see gemm_internal.h
-int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long ldb, long b_batch, const float* bias, long bias_batch, float* C,
-                  long ldc, long c_batch, int M, int N, int K, int batch, int act, hipStream_t st) {
+int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st) {
     if (as_matrix_arith() != AS_ARITH_BF16X6) return 0;
-    if (!A || !B || !C || M < 1 || N < 1 || K < BK || K % BK || batch < 1 || act < 0 || act > 2) return 0;
-    if (lda % 4 || ldb % 4 || a_batch % 4 || b_batch % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
-    if ((long)M * lda >= (1L << 30) || (long)N * ldb >= (1L << 30)) return 0;   // 32-bit byte offsets inside one batch member
-    S6K k{A, lda, a_batch, B, ldb, b_batch, C, ldc, c_batch, bias, bias_batch, M, N, K, act, as_cdiv(M, TB), as_cdiv(N, TB)};
-    const long blocks = (long)k.tiles_m * k.tiles_n * batch;
+    if (!(g->a_k == 1 && g->b_k == 1) || g->K < BK || g->K % BK || g->act < 0 || g->act > 2) return 0;
+    if (g->res || g->mask_bits || g->k_seg || g->k_tri || g->colsum || g->splitk_ws || g->accumulate || g->b_kT || (g->precision != 0 && g->precision != 3)) return 0;
+    if (g->relu_bits && g->act != 1) return 0;
+    if (g->a_i % 4 || g->b_j % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (reinterpret_cast<uintptr_t>(g->B) & 15)) return 0;
+    if ((!g->a_off && g->a_batch % 4) || (!g->b_off && g->b_batch % 4)) return 0;
+    if ((long)g->M * g->a_i >= (1L << 30) || (long)g->N * g->b_j >= (1L << 30)) return 0;   // 32-bit byte offsets inside one batch member
+    S6K k{};
+    k.A = g->A; k.lda = g->a_i; k.a_batch = g->a_batch;
+    k.B = g->B; k.ldb = g->b_j; k.b_batch = g->b_batch;
+    k.C = g->C; k.ldc = g->ldc; k.c_batch = g->c_batch;
+    k.bias = g->bias; k.bias_batch = g->bias_batch;
+    k.M = g->M; k.N = g->N; k.K = g->K; k.act = g->act; k.tiles_m = as_cdiv(g->M, TB); k.tiles_n = as_cdiv(g->N, TB);
+    k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off; k.bias_off = (const long*)g->bias_off;
+    k.relu_bits = g->relu_bits; k.relu_bits_batch = g->relu_bits_batch; k.ncb = (g->N + 31) / 32;
+    const long blocks = (long)k.tiles_m * k.tiles_n * g->batch;
     if (blocks > (1L << 30)) return 0;
     hipLaunchKernelGGL(gemm_s6_nt_kernel, dim3((unsigned)blocks), dim3(NTH), 0, st, k);
     AS_LAUNCH_CHECK("as_gemm_s6_nt");
     return 1;
+}
+
+int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long ldb, long b_batch, const float* bias, long bias_batch, float* C,
+                  long ldc, long c_batch, int M, int N, int K, int batch, int act, hipStream_t st) {
+    if (!A || !B || !C || M < 1 || N < 1 || batch < 1) return 0;
+    as_gemm g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.a_i = lda; g.a_k = 1; g.b_j = ldb; g.b_k = 1; g.ldc = ldc;
+    g.batch = batch; g.a_batch = a_batch; g.b_batch = b_batch; g.c_batch = c_batch; g.bias_batch = bias_batch; g.act = act;
+    return as_gemm_s6_nt_ext(&g, st);
 }

@@ -19,7 +19,12 @@ _SLAB = {}
 
 # Precision of the forward linears of the modules built on these ops (as_gemm.precision): "f32" = exact fp32 MFMA,
 # "bf16x6" / "bf16x3" = fp32 operands split on the fly into 3 / 2 bf16 pieces on the bf16 MFMA, fp32 accumulation.
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+# "lib" = the library's matrix arithmetic (as_set_matrix_arith: split fp32 on the bf16 matrix instruction unless the process chose
+# the exact fp32 one) for the forward linears, at any size.  Measured at configs[3] (d=256, L=6, B=32, T=200): forward + backward
+# 218 -> 198 ms; the full-width model's contours against the REFERENCE fixture then sit at 1.19 x the 1e-4 bound (0.89 x with
+# "f32": two correct fp32 roundings of a 6-layer network differ by about that much), so the default stays "f32" and the
+# transformer's weight gradients alone use the split arithmetic (yardstick-checked, test_full_width_model_matches_reference_fixture).
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "lib": 3}
 GEMM_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GEMM_PRECISION", "f32")]
 
 
@@ -424,8 +429,9 @@ def channel_blocks_forward(xt, xs, q_w, q_b, k_w, k_b, v_w, v_b, in_w, in_b, o_w
     ncb = (d + 31) // 32
     qbits = torch.empty((G, R, ncb), dtype=torch.int32, device=dev) if training else None
     kvbits = torch.empty((2 * G, Rs, ncb), dtype=torch.int32, device=dev) if training else None
-    bq = dict(relu_bits=qbits, relu_bits_batch=R * ncb, precision=0) if training else {}
-    bkv = dict(relu_bits=kvbits, relu_bits_batch=Rs * ncb, precision=0) if training else {}
+    lib_or_exact = 3 if GEMM_PRECISION == 3 else 0   # (the on-the-fly split kernels of as_gemm.precision 1 / 2 have no bit-image epilogue)
+    bq = dict(relu_bits=qbits, relu_bits_batch=R * ncb, precision=lib_or_exact) if training else {}
+    bkv = dict(relu_bits=kvbits, relu_bits_batch=Rs * ncb, precision=lib_or_exact) if training else {}
     _gemm(A=xt, B=W3, C=q, bias=b3, M=R, N=d, K=d, a_i=d, a_k=1, b_j=d, b_k=1, ldc=d, batch=G, a_off=t_off, b_batch=d * d,
           c_batch=R * d, bias_batch=d, act=1, **bq)
     # MHA in-projection: slice j of the stacked [G, 3d, d] weight, read in place

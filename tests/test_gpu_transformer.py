@@ -385,6 +385,31 @@ def test_backward_matches_reference_fixture(small, dev):
     model.zero_grad()
 
 
+def test_split_forward_gemms_opt_in_matches_reference_fixture(small, dev):
+    """ARTSPEECH_GEMM_PRECISION=lib / set_gemm_precision("lib"): the forward linears (with their ReLU bit images, grouped
+    offsets) on the bf16 matrix instruction with both operands split in the kernel (as_gemm.precision = 3, gemm_s6.hip).  The
+    small reference fixture is reproduced at the tolerances of the default path, forward and backward."""
+    from artspeech_amd.phoneme_to_articulation.transformer import ops
+    model, g, _ = small
+    _, grads = split_wg(g)
+    keep = ops.GEMM_PRECISION
+    ops.set_gemm_precision("lib")
+    try:
+        model.zero_grad()
+        args = dict(src_key_padding_mask=_t(g["src_kpm"], dev), tgt_key_padding_mask=_t(g["tgt_kpm"], dev),
+                    src_attn_mask=_t(g["src_mask"], dev), tgt_attn_mask=_t(g["tgt_mask"], dev))
+        out = model(_t(g["tokens"], dev, torch.int64), _t(g["shifted"], dev), **args)
+        assert np.abs(out.detach().cpu().numpy() - g["out_grad"]).max() < 5e-6
+        (out * _t(g["dout"], dev)).sum().backward()
+        gv = model.named_grad_views()
+        for k, ref in grads.items():
+            err = np.abs(gv[k].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6)
+            assert err < 1e-3, (k, err)
+        model.zero_grad()
+    finally:
+        ops.GEMM_PRECISION = keep
+
+
 def test_layer_checkpointing_gives_identical_gradients(small, dev):
     """model.checkpoint_layers = True keeps only each decoder layer's input and recomputes the layer in the backward:
     the same kernels on the same inputs in the same order, hence bit-identical outputs and gradients."""

@@ -13,13 +13,14 @@ L = _lib.lib()
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [("GRU input projection", 6400, 768, 256), ("trunk Linear", 6400, 128, 256), ("GRU input gradient", 6400, 256, 768),
-          ("transformer block Linear x 8", 51200, 256, 256), ("big", 51200, 1024, 1024)]
+          ("transformer block Linear x 8", 51200, 256, 256), ("transformer block group x 110 (as one matrix)", 704000, 256, 256),
+          ("big", 51200, 1024, 1024)]
 for name, M, N, K in SHAPES:
     torch.manual_seed(0)
     a = torch.randn(M, K, device=dev)
     w = (torch.rand(N, K, device=dev) * 2 - 1) / K ** 0.5
     b = torch.zeros(N, device=dev)
-    ref = a.double() @ w.double().T
+    ref = a[:51200].double() @ w.double().T      # (error measured on the first 51200 rows)
     out = torch.empty(M, N, device=dev)
     pw = torch.empty(max(64, L.as_linear_planes_floats(N, K)), device=dev)
     print(f"{name}: M={M} N={N} K={K}  {2e-9 * M * N * K:.2f} GFLOP")
@@ -37,6 +38,6 @@ for name, M, N, K in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        err = (out.double() - ref)
+        err = (out[:51200].double() - ref)
         print(f"  {label:24s} {us:8.1f} us  {2e-6 * M * N * K / us:7.1f} TF/s   rms err / rms C {(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item():.2e}")
 L.as_set_matrix_arith(1)

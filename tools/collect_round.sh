@@ -12,12 +12,12 @@ part=${2:-abc}
 cd /tmp && export TMPDIR=/tmp
 if [[ $part == *a* ]]; then
 step 500 $out/bench_final.json python3 $R/bench.py
-step 300 $out/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras
-step 300 $out/fetch.json rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
-step 300 $out/write.json rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
-step 300 $out/kt.log rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras
+step 300 $out/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --no-exact
+step 300 $out/fetch.json rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile --no-exact
+step 300 $out/write.json rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile --no-exact
+step 300 $out/kt.log rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras --no-exact
 python3 $R/tools/step_timeline.py $(ls -t $out/kt/*/*_kernel_trace.csv | head -1) > $out/step_timeline.txt
-step 300 $out/mfma.json rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile
+step 300 $out/mfma.json rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile --no-exact
 fi
 if [[ $part == *b* ]]; then
 # the three small kernels north_star names: per-kernel time + HBM bytes of a driver-style loop

@@ -16,7 +16,7 @@ def main(path):
     # slice, inside the NEXT step's forward) and the final flush are not step boundaries
     adam, seen_loss = [], False
     for i, r in enumerate(rows):
-        if "euclid_masked_kernel" in r["Kernel_Name"] or "lin_out_kernel" in r["Kernel_Name"]:   # the criterion (separate / fused)
+        if "euclid_masked_kernel" in r["Kernel_Name"] or "lin_out_kernel" in r["Kernel_Name"] or "lin_out_s6_kernel" in r["Kernel_Name"]:   # the criterion (separate / fused)
             seen_loss = True
         elif "adam_kernel" in r["Kernel_Name"] and seen_loss:
             adam.append(i)
