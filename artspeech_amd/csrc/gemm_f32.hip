@@ -851,7 +851,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     // operands split inside the kernel (gemm_s6.hip: 1.36 x this kernel on the transformer's block groups, 110 x [6400 x 256 x
     // 256]).  Opt-in per call and independent of the launch's size: a size threshold would make the last bits of a result
     // depend on the batch it was computed in (measured: 7e-5 on the transformer's contours between batches of 4 and 32).
-    if (a_kc && b_kc && g->precision == 3) {
+    // The input-gradient orientation (B column-contiguous, with res / mask_bits / k_seg) goes the same way.
+    if (a_kc && (b_kc || g->b_j == 1) && g->precision == 3) {
         const int took = as_gemm_s6_nt_ext(g, st);
         if (took != 0) return took < 0 ? took : 0;
     }

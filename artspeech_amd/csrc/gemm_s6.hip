@@ -22,6 +22,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -40,6 +41,11 @@ struct S6K {
     // a ReLU epilogue (as_gemm.relu_bits: [batch][M][ceil(N / 32)] words, bit n % 32 of word n / 32 = result > 0)
     const long* a_off; const long* b_off; const long* c_off; const long* bias_off;
     unsigned* relu_bits; long relu_bits_batch; int ncb;
+    // the general kernel's extended operands (gemm_f32.hip; input-gradient shapes): initial value of the accumulators, the bit
+    // image of a ReLU backward (elements whose bit is clear are stored as 0), segmented reduction
+    const float* res; long res_ld, res_batch; const long* res_off;
+    const unsigned* mask_bits; long mask_batch;
+    int k_seg, nseg; const long* a_seg_off; const long* b_seg_off;
 };
 
 typedef const __attribute__((address_space(1))) char* gptr;
@@ -50,7 +56,11 @@ __device__ __forceinline__ gptr uniform_ptr(const void* p) {   // see lin_f32.hi
     return reinterpret_cast<gptr>(((uintptr_t)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
+// BNC: the B operand is column-contiguous in memory, B[k][n] (an input gradient dx = dz . W with W as the forward stores it):
+// a thread then loads 8 consecutive k of ONE column (8 dword loads, each coalesced over the 64 columns of its wave) and writes
+// 16 bytes per plane.  EXT: res / mask_bits / k_seg.
+template <bool BNC, bool EXT>
+__global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * BUF];
     // block -> (batch, n-tile, m-tile): the m-tiles of one (batch, n-tile) are consecutive (they share the B panel in L2)
     int t = blockIdx.x;
@@ -63,8 +73,13 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
     const int wm = wave >> 1, wn = wave & 1;
     // loads: thread -> rows (tid >> 2) and (tid >> 2) + 64 of each operand tile, 16-byte chunk tid & 3 of the row's 16 k
     const int lrow = tid >> 2, lch = tid & 3;
-    const gptr Au = uniform_ptr(g.A + (g.a_off ? g.a_off[bz] : (long)bz * g.a_batch));
-    const gptr Bu = uniform_ptr(g.B + (g.b_off ? g.b_off[bz] : (long)bz * g.b_batch));
+    const bool seg = EXT && g.k_seg > 0;
+    const long* a_seg = seg ? g.a_seg_off + (long)bz * g.nseg : nullptr;
+    const long* b_seg = seg ? g.b_seg_off + (long)bz * g.nseg : nullptr;
+    gptr Au = uniform_ptr(g.A + (seg ? a_seg[0] : g.a_off ? g.a_off[bz] : (long)bz * g.a_batch));
+    gptr Bu = uniform_ptr(g.B + (seg ? b_seg[0] : g.b_off ? g.b_off[bz] : (long)bz * g.b_batch));
+    // the NEXT segment's bases are fetched a segment ahead (scalar loads that have 16 k-tiles to arrive)
+    long a_next = seg ? a_seg[min(1, g.nseg - 1)] : 0, b_next = seg ? b_seg[min(1, g.nseg - 1)] : 0;
     unsigned a_off[2], b_off[2];
     int wr[2];
 #pragma unroll
@@ -74,31 +89,89 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
         b_off[q] = (unsigned)((long)min(n0 + r, g.N - 1) * g.ldb + lch * 4) * 4u;
         wr[q] = r * 32 + (((lch >> 1) ^ ((r >> 3) & 1)) * 16) + (lch & 1) * 8;
     }
+    // BNC: column n0 + (tid & 127), k half tid >> 7 (8 consecutive k); byte step between two k = 4 * ldb
+    const int bn = tid & 127, bkh = tid >> 7;
+    const unsigned ldb4 = (unsigned)g.ldb * 4u;
+    const unsigned bnc_off = (unsigned)min(n0 + bn, g.N - 1) * 4u + (unsigned)(bkh * 8) * ldb4;
+    const int bnc_wr = bn * 32 + ((bkh ^ ((bn >> 3) & 1)) * 16);
     const int nk = g.K / BK;
+    const int kspan = seg ? g.k_seg : g.K;     // k range addressed from the current bases
+    int ld_t = 0, ld_k = 0, ld_seg = 0;        // the next load: k-tile, k inside the segment, segment (all wave-uniform)
     struct Regs { f32x4 a[2], b[2]; };
-    auto load = [&](Regs& x, int kt) {
-        const unsigned ko = (unsigned)(min(kt, nk - 1) * BK) * 4u;
+    auto load = [&](Regs& x) {
+        const unsigned ko = (unsigned)ld_k * 4u;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            x.a[q] = *reinterpret_cast<gptr_f4>(Au + (a_off[q] + ko));
-            x.b[q] = *reinterpret_cast<gptr_f4>(Bu + (b_off[q] + ko));
+        for (int q = 0; q < 2; ++q) x.a[q] = *reinterpret_cast<gptr_f4>(Au + (a_off[q] + ko));
+        if constexpr (!BNC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) x.b[q] = *reinterpret_cast<gptr_f4>(Bu + (b_off[q] + ko));
+        } else {
+            const unsigned kb = bnc_off + (unsigned)ld_k * ldb4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x.b[q][e] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(Bu + (kb + (unsigned)(q * 4 + e) * ldb4));
+        }
+        // advance (behind the last tile the loads repeat it: unconditional loads keep hipcc's vmcnt counts exact)
+        if constexpr (!EXT) {
+            ld_t = min(ld_t + 1, nk - 1);
+            ld_k = ld_t * BK;
+        } else if (ld_t + 1 < nk) {
+            ++ld_t;
+            ld_k += BK;
+            if (ld_k == kspan) {
+                ld_k = 0;
+                ++ld_seg;
+                Au = uniform_ptr(g.A + a_next);
+                Bu = uniform_ptr(g.B + b_next);
+                const int nx = min(ld_seg + 1, g.nseg - 1);
+                a_next = a_seg[nx];
+                b_next = b_seg[nx];
+            }
         }
     };
     auto store = [&](const Regs& x, int buf) {
         unsigned char* base = sm + buf * BUF;
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 v = x.a[q];
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split_pair(v.x, v.y, h0, m0_, l0);
+            split_pair(v.z, v.w, h1, m1, l1);
+            unsigned char* d = base + wr[q];
+            *reinterpret_cast<u32x2*>(d) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(d + PLANE) = (u32x2){m0_, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * PLANE) = (u32x2){l0, l1};
+        }
+        if constexpr (!BNC) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 v = o == 0 ? x.a[q] : x.b[q];
+                const f32x4 v = x.b[q];
                 unsigned h0, m0_, l0, h1, m1, l1;
                 split_pair(v.x, v.y, h0, m0_, l0);
                 split_pair(v.z, v.w, h1, m1, l1);
-                unsigned char* d = base + o * OPER + wr[q];
+                unsigned char* d = base + OPER + wr[q];
                 *reinterpret_cast<u32x2*>(d) = (u32x2){h0, h1};
                 *reinterpret_cast<u32x2*>(d + PLANE) = (u32x2){m0_, m1};
                 *reinterpret_cast<u32x2*>(d + 2 * PLANE) = (u32x2){l0, l1};
             }
+        } else {
+            u32x4 h, m, l;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split_pair(x.b[q].x, x.b[q].y, h0, m0_, l0);
+                split_pair(x.b[q].z, x.b[q].w, h1, m1, l1);
+                h[2 * q] = h0; h[2 * q + 1] = h1;
+                m[2 * q] = m0_; m[2 * q + 1] = m1;
+                l[2 * q] = l0; l[2 * q + 1] = l1;
+            }
+            unsigned char* d = base + OPER + bnc_wr;
+            *reinterpret_cast<u32x4*>(d) = h;
+            *reinterpret_cast<u32x4*>(d + PLANE) = m;
+            *reinterpret_cast<u32x4*>(d + 2 * PLANE) = l;
+        }
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -112,15 +185,29 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
     const unsigned char* b_rd = sm + OPER + (wn * 64 + l31) * 32 + fsw * 16;
 
     Regs x[2];
-    load(x[0], 0);
-    load(x[1], 1);
+    load(x[0]);
+    load(x[1]);
+    if (EXT && g.res) {   // the accumulators start from `res` (requested behind the first two tiles' loads)
+        const float* R = g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M && col < g.N) acc[i][j][r] = R[(long)row * g.res_ld + col];
+                }
+        }
+    }
     store(x[0], 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // k-tile kt (U = kt & 1): images in buffer U; x[U ^ 1] holds tile kt + 1, x[U] is refilled with tile kt + 2
-    auto tile = [&](auto Uc, int kt) {
+    auto tile = [&](auto Uc) {
         constexpr int U = decltype(Uc)::value;
-        load(x[U], kt + 2);
+        load(x[U]);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
@@ -144,15 +231,16 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
     };
     int kt = 0;
     for (; kt + 2 <= nk; kt += 2) {
-        tile(IC2<0>{}, kt);
-        tile(IC2<1>{}, kt + 1);
+        tile(IC2<0>{});
+        tile(IC2<1>{});
     }
-    if (kt < nk) tile(IC2<0>{}, kt);
+    if (kt < nk) tile(IC2<0>{});
 
     // ---- epilogue: D[i][j] block (i, j) of the wave: row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = n0 + wn * 64 + j * 32 + l31
     float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
     const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
     if (g.relu_bits == nullptr) {
+        const unsigned* mask = (EXT && g.mask_bits) ? g.mask_bits + (long)bz * g.mask_batch : nullptr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + l31;
@@ -167,6 +255,7 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
                         float v = acc[i][j][r] + bj;
                         if (g.act == 1) v = as_relu(v);
                         else if (g.act == 2) v = as_sigmoid(v);
+                        if (EXT && mask && !((mask[(long)row * g.ncb + (col >> 5)] >> l31) & 1u)) v = 0.f;
                         C[(long)row * g.ldc + col] = v;
                     }
                 }
@@ -209,24 +298,40 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_nt_kernel(S6K g) {
 // see gemm_internal.h
 int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st) {
     if (as_matrix_arith() != AS_ARITH_BF16X6) return 0;
-    if (!(g->a_k == 1 && g->b_k == 1) || g->K < BK || g->K % BK || g->act < 0 || g->act > 2) return 0;
-    if (g->res || g->mask_bits || g->k_seg || g->k_tri || g->colsum || g->splitk_ws || g->accumulate || g->b_kT || (g->precision != 0 && g->precision != 3)) return 0;
-    if (g->relu_bits && g->act != 1) return 0;
-    if (g->a_i % 4 || g->b_j % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (reinterpret_cast<uintptr_t>(g->B) & 15)) return 0;
-    if ((!g->a_off && g->a_batch % 4) || (!g->b_off && g->b_batch % 4)) return 0;
-    if ((long)g->M * g->a_i >= (1L << 30) || (long)g->N * g->b_j >= (1L << 30)) return 0;   // 32-bit byte offsets inside one batch member
+    const bool bnc = g->b_k != 1;     // B[k][n], n contiguous (input-gradient orientation)
+    if (g->a_k != 1 || (bnc && g->b_j != 1) || g->K < BK || g->K % BK || g->act < 0 || g->act > 2) return 0;
+    if (g->k_tri || g->colsum || g->splitk_ws || g->accumulate || g->b_kT || g->b_kshift || (g->precision != 0 && g->precision != 3)) return 0;
+    const bool ext = g->res || g->mask_bits || g->k_seg;
+    if (g->relu_bits && (g->act != 1 || ext)) return 0;
+    if (g->a_i % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (!g->a_off && !g->k_seg && g->a_batch % 4)) return 0;
+    if (!bnc && (g->b_j % 4 || (reinterpret_cast<uintptr_t>(g->B) & 15) || (!g->b_off && !g->k_seg && g->b_batch % 4))) return 0;
+    if (g->k_seg && (g->k_seg % BK || g->K % g->k_seg || !g->a_seg_off || !g->b_seg_off)) return 0;
+    const long kspan = g->k_seg ? g->k_seg : g->K;
+    // 32-bit byte offsets inside one batch member / segment
+    if ((long)g->M * g->a_i >= (1L << 30) || (bnc ? kspan * g->b_k + g->N : (long)g->N * g->b_j) >= (1L << 30)) return 0;
     S6K k{};
     k.A = g->A; k.lda = g->a_i; k.a_batch = g->a_batch;
-    k.B = g->B; k.ldb = g->b_j; k.b_batch = g->b_batch;
+    k.B = g->B; k.ldb = bnc ? g->b_k : g->b_j; k.b_batch = g->b_batch;
     k.C = g->C; k.ldc = g->ldc; k.c_batch = g->c_batch;
     k.bias = g->bias; k.bias_batch = g->bias_batch;
     k.M = g->M; k.N = g->N; k.K = g->K; k.act = g->act; k.tiles_m = as_cdiv(g->M, TB); k.tiles_n = as_cdiv(g->N, TB);
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off; k.bias_off = (const long*)g->bias_off;
     k.relu_bits = g->relu_bits; k.relu_bits_batch = g->relu_bits_batch; k.ncb = (g->N + 31) / 32;
+    k.res = g->res; k.res_ld = g->res_ld; k.res_batch = g->res_batch; k.res_off = (const long*)g->res_off;
+    k.mask_bits = g->mask_bits; k.mask_batch = g->mask_batch;
+    k.k_seg = g->k_seg; k.nseg = g->k_seg ? g->K / g->k_seg : 1;
+    k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
     const long blocks = (long)k.tiles_m * k.tiles_n * g->batch;
     if (blocks > (1L << 30)) return 0;
-    hipLaunchKernelGGL(gemm_s6_nt_kernel, dim3((unsigned)blocks), dim3(NTH), 0, st, k);
-    AS_LAUNCH_CHECK("as_gemm_s6_nt");
+    const dim3 grid((unsigned)blocks), blk(NTH);
+    if (ext) {
+        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<true, true>), grid, blk, 0, st, k);
+        else hipLaunchKernelGGL((gemm_s6_kernel<false, true>), grid, blk, 0, st, k);
+    } else {
+        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<true, false>), grid, blk, 0, st, k);
+        else hipLaunchKernelGGL((gemm_s6_kernel<false, false>), grid, blk, 0, st, k);
+    }
+    AS_LAUNCH_CHECK("as_gemm_s6");
     return 1;
 }
 

@@ -340,6 +340,146 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_row_kernel(const float* __rest
     if (s + 1 < len) step(s + 1, bq, a);
 }
 
+// ---- any hidden size (nn.LSTM takes any, principal_components/models/rnn.py:58-68): plain kernels for the sizes the
+// register-resident ones above are not built for (gru.hip has the same pair for the GRU).  One workgroup of 1024 threads per
+// (utterance, direction), h and c in LDS, W_hh streamed from L2 every step.  Same gates / y / dg layouts and packed-sequence
+// semantics; the reduction order over k differs from the kernels above in the last bits.  A correct fallback, not a tuned path.
+constexpr int GEN_THREADS = 1024;
+
+// Forward: four adjacent lanes share a hidden unit; lane q takes the 16-byte chunks q, q + 4, ... of the unit's four W_hh rows
+// (the quad reads 64 consecutive bytes of a row), four chunks = 16 global loads in flight per pass.  H % 4 == 0.
+template <bool TRAIN, bool TOK>
+__global__ __launch_bounds__(GEN_THREADS) void lstm_fwd_generic_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
+                                                                      long tok_stride, const float* __restrict__ w_hh,
+                                                                      const float* __restrict__ b_hh, const int* __restrict__ lengths,
+                                                                      int T, int H, float* __restrict__ y, float* __restrict__ gates) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // h double buffer [2][H], c [H]
+    float* cb = gsm + 2 * H;
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int q = tid & 3;
+    const int len = lengths[b];
+    for (long i = (long)len * H + tid; i < (long)T * H; i += GEN_THREADS)   // pad_packed_sequence: exact zeros
+        y[((long)b * T + i / H) * 2 * H + dir * H + (i % H)] = 0.f;
+    for (int j = tid; j < 3 * H; j += GEN_THREADS) gsm[j] = 0.f;
+    __syncthreads();
+    if (len <= 0) return;
+    const float* wd = w_hh + (long)dir * 4 * H * H;
+    const float* bd = b_hh + (long)dir * 4 * H;
+    const int nch = H >> 2;   // 16-byte chunks per row
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? len - 1 - s : s;
+        const long frame = (long)b * T + t;
+        const float* hc = gsm + (s & 1) * H;
+        float* hn_ = gsm + ((s & 1) ^ 1) * H;
+        const float* gr = gi + (TOK ? tokens[(long)b * tok_stride + t] * 8L * H : frame * 8L * H) + (long)dir * 4 * H;
+        for (int j = tid >> 2; j < H; j += GEN_THREADS / 4) {   // (the four lanes of a quad share j: the DPP sums are whole)
+            const float4* h4 = reinterpret_cast<const float4*>(hc);
+            float sg[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c0 = q; c0 < nch; c0 += 16) {
+                float4 wv[4][4], hv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {      // branch-free: chunks beyond the row re-read its last one against a zero h
+                    const int cc = c0 + 4 * u;
+                    const int ci = cc < nch ? cc : nch - 1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) wv[g][u] = reinterpret_cast<const float4*>(wd + (long)(g * H + j) * H)[ci];
+                    hv[u] = h4[ci];
+                    if (cc >= nch) hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        sg[g] += wv[g][u].x * hv[u].x + wv[g][u].y * hv[u].y + wv[g][u].z * hv[u].z + wv[g][u].w * hv[u].w;
+            }
+            const float gi_ = as_sigmoid(gr[j] + quad_sum(sg[0]) + bd[j]);
+            const float gf = as_sigmoid(gr[H + j] + quad_sum(sg[1]) + bd[H + j]);
+            const float gg = as_tanh(gr[2 * H + j] + quad_sum(sg[2]) + bd[2 * H + j]);
+            const float go = as_sigmoid(gr[3 * H + j] + quad_sum(sg[3]) + bd[3 * H + j]);
+            const float cnew = gf * cb[j] + gi_ * gg;     // (the quad's lanes read c before lane 0 writes it: one wave, program order)
+            const float hnew = go * as_tanh(cnew);
+            if (q == 0) {
+                cb[j] = cnew;
+                hn_[j] = hnew;
+                y[frame * 2 * H + dir * H + j] = hnew;
+                if (TRAIN) {
+                    float* gp = gates + frame * 10L * H + (long)dir * 5 * H + j;
+                    gp[0] = gi_; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go; gp[4 * H] = cnew;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Backward: the four gate gradients of a step by one thread per hidden unit; then dh = W_hh^T p with the 4H gate rows dealt
+// over four thread groups (lanes = consecutive hidden columns: a wave reads 256 consecutive bytes of a row, eight rows in
+// flight), the four partial sums meeting in LDS in a fixed order.
+__global__ __launch_bounds__(GEN_THREADS) void lstm_bwd_generic_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
+                                                                      const float* __restrict__ w_hh, const int* __restrict__ lengths,
+                                                                      int T, int H, float* __restrict__ dg) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // p [4H], dh carried [H], dc carried [H], partial sums [4][H]
+    float* gb = gsm;
+    float* dhb = gsm + 4 * H;
+    float* dcb = gsm + 5 * H;
+    float* part = gsm + 6 * H;
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int len = lengths[b];
+    for (long i = (long)len * 4 * H + tid; i < (long)T * 4 * H; i += GEN_THREADS) {   // padded frames feed the time-batched GEMMs as zeros
+        const long t = i / (4 * H), c = i % (4 * H);
+        dg[(((long)b * T + t) * 2 + dir) * 4 * H + c] = 0.f;
+    }
+    for (int j = tid; j < 2 * H; j += GEN_THREADS) dhb[j] = 0.f;   // dh and dc
+    __syncthreads();
+    if (len <= 0) return;
+    const float* wd = w_hh + (long)dir * 4 * H * H;
+    const int dt = dir ? 1 : -1;   // opposite to the forward walk; c_prev of frame t is the cell state of the frame visited NEXT
+    const int kq = tid >> 8, kl = tid & 255;   // row group (0..3), column within a block of 256
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? s : len - 1 - s;
+        const long frame = (long)b * T + t;
+        const bool has_prev = s + 1 < len;
+        for (int j = tid; j < H; j += GEN_THREADS) {
+            const float* gp = gates + frame * 10L * H + (long)dir * 5 * H + j;
+            const float gi_ = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H], c = gp[4 * H];
+            const float cprev = has_prev ? gates[(frame + dt) * 10L * H + (long)dir * 5 * H + 4 * H + j] : 0.f;
+            const float dht = dhb[j] + dy[frame * 2 * H + dir * H + j];
+            const float tc = as_tanh(c);
+            const float dct = dcb[j] + dht * go * (1.f - tc * tc);
+            const float p_o = dht * tc * go * (1.f - go);
+            const float p_i = dct * gg * gi_ * (1.f - gi_);
+            const float p_f = dct * cprev * gf * (1.f - gf);
+            const float p_g = dct * gi_ * (1.f - gg * gg);
+            dcb[j] = dct * gf;
+            float* d = dg + (frame * 2 + dir) * 4L * H + j;
+            d[0] = p_i; d[H] = p_f; d[2 * H] = p_g; d[3 * H] = p_o;
+            gb[j] = p_i; gb[H + j] = p_f; gb[2 * H + j] = p_g; gb[3 * H + j] = p_o;
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < H; k0 += 256) {
+            const int k = k0 + kl;
+            const int kc = k < H ? k : H - 1;
+            float acc = 0.f;
+            for (int i0 = kq; i0 < 4 * H; i0 += 32) {   // rows kq, kq + 4, ...: eight of them in flight
+                float wv[8], gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 4 * u;
+                    const int ic = i < 4 * H ? i : 4 * H - 1;
+                    wv[u] = wd[(long)ic * H + kc];
+                    gv[u] = i < 4 * H ? gb[ic] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += gv[u] * wv[u];
+            }
+            if (k < H) part[kq * H + k] = acc;
+        }
+        __syncthreads();
+        for (int k = tid; k < H; k += GEN_THREADS) dhb[k] = (part[k] + part[H + k]) + (part[2 * H + k] + part[3 * H + k]);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int as_lstm_bidir_fwd(const float* gi, const int64_t* tokens, int64_t tok_stride, const float* w_hh, const float* b_hh,
@@ -361,9 +501,17 @@ extern "C" int as_lstm_bidir_fwd(const float* gi, const int64_t* tokens, int64_t
         case 32: AS_LSTM_FWD(32) break;
         case 64: AS_LSTM_FWD(64) break;
         case 128: AS_LSTM_FWD(128) break;
-        default:
-            as_set_error("as_lstm_bidir_fwd: hidden size %d not in {32, 64, 128}", H);
-            return AS_ERR_UNSUPPORTED;
+        default: {   // any other hidden size: the plain kernels
+            const size_t gshm = (size_t)3 * H * sizeof(float);
+            AS_REQUIRE(H > 0 && H % 4 == 0 && gshm <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_lstm_bidir_fwd: hidden size %d (a multiple of 4 up to 5460)", H);
+#define AS_LSTM_GEN(TR, TK) \
+    hipLaunchKernelGGL((lstm_fwd_generic_kernel<TR, TK>), grid, dim3(GEN_THREADS), gshm, st, gi, tokens, (long)tok_stride, w_hh, b_hh, lengths, T, H, y, gates)
+            if (gates && tokens) AS_LSTM_GEN(true, true);
+            else if (gates) AS_LSTM_GEN(true, false);
+            else if (tokens) AS_LSTM_GEN(false, true);
+            else AS_LSTM_GEN(false, false);
+#undef AS_LSTM_GEN
+        }
     }
 #undef AS_LSTM_FWD
 #undef AS_LSTM_LAUNCH
@@ -389,9 +537,11 @@ extern "C" int as_lstm_bidir_bwd(const float* dy, const float* gates, const floa
         case 32: AS_LSTM_BWD(32); break;
         case 64: AS_LSTM_BWD(64); break;
         case 128: AS_LSTM_BWD(128); break;
-        default:
-            as_set_error("as_lstm_bidir_bwd: hidden size %d not in {32, 64, 128}", H);
-            return AS_ERR_UNSUPPORTED;
+        default: {   // any other hidden size: the plain kernel
+            const size_t gshm = (size_t)10 * H * sizeof(float);
+            AS_REQUIRE(H > 0 && H % 4 == 0 && gshm <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_lstm_bidir_bwd: hidden size %d (a multiple of 4 up to 1636)", H);
+            hipLaunchKernelGGL(lstm_bwd_generic_kernel, grid, dim3(GEN_THREADS), gshm, st, dy, gates, w_hh, lengths, T, H, dg);
+        }
     }
 #undef AS_LSTM_BWD
     AS_LAUNCH_CHECK("as_lstm_bidir_bwd");

@@ -28,9 +28,18 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "lib": 3}
 GEMM_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GEMM_PRECISION", "f32")]
 
 
-def set_gemm_precision(name):
-    global GEMM_PRECISION
+# Precision of the INPUT-GRADIENT GEMMs (dx = dz W, with their residual / ReLU-mask / segmented-reduction operands): the library's
+# matrix arithmetic by default.  Gradients are held to the oracle by a yardstick relative to their own magnitude and the split
+# product is at least as accurate as the fp32 instruction's (tests/test_gpu_parity.py::test_split_matrix_arithmetic_error_vs_fp64),
+# so nothing a forward value is compared with depends on this.  ARTSPEECH_GRAD_PRECISION=f32 keeps them on the fp32 instruction.
+GRAD_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GRAD_PRECISION", "lib")]
+
+
+def set_gemm_precision(name, grad=None):
+    global GEMM_PRECISION, GRAD_PRECISION
     GEMM_PRECISION = PRECISIONS[name]
+    if grad is not None:
+        GRAD_PRECISION = PRECISIONS[grad]
 
 
 def _gemm(**kw):
@@ -237,7 +246,7 @@ class GroupedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             part = torch.empty((G, R, K), dtype=torch.float32, device=x.device)
             _gemm(A=dz, B=W, C=part, M=R, N=K, K=N, a_i=N, a_k=1, b_j=1, b_k=K, ldc=K, batch=G, a_batch=R * N, b_batch=N * K,
-                  c_batch=R * K)
+                  c_batch=R * K, precision=GRAD_PRECISION)
             if identity:
                 dx = part
             else:
@@ -552,7 +561,8 @@ class ChannelBlocks(torch.autograd.Function):
         same = R == Rs
         # ---- out-projection: d ctx = dout Wo ; dWo = dout^T ctx (+ its bias gradient as the column sums of dout)
         datt = new(G, R, d)
-        _gemm(A=dout, B=o_w, C=datt, M=R, N=d, K=d, a_i=ldo, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, b_batch=d * d, c_batch=R * d, **a_lay)
+        _gemm(A=dout, B=o_w, C=datt, M=R, N=d, K=d, a_i=ldo, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, b_batch=d * d, c_batch=R * d,
+              precision=GRAD_PRECISION, **a_lay)
         do_w, do_b = new(G, d, d), new(G, d)
         _gemm(A=dout, B=att, C=do_w, M=d, N=d, K=R, a_i=1, a_k=ldo, b_j=1, b_k=d, ldc=d, batch=G, b_batch=R * d, c_batch=d * d,
               colsum=do_b, colsum_batch=d, **a_lay, **ws)
@@ -571,9 +581,9 @@ class ChannelBlocks(torch.autograd.Function):
         dq, dkv = new(G, R, d), new(2, G, Rs, d)
         w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
         _gemm(A=dq2, B=in_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=3 * d * d,
-              c_batch=R * d, mask_bits=qbits, mask_batch=R * ncb, precision=0, **r_lay)
+              c_batch=R * d, mask_bits=qbits, mask_batch=R * ncb, precision=GRAD_PRECISION, **r_lay)
         _gemm(A=dkv2, B=in_w, C=dkv, M=Rs, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d, b_off=w_off[G:],
-              c_batch=Rs * d, mask_bits=kvbits, mask_batch=Rs * ncb, precision=0)
+              c_batch=Rs * d, mask_bits=kvbits, mask_batch=Rs * ncb, precision=GRAD_PRECISION)
         del dp2, dq2, dkv2
         # ---- pre-projections: gradients of the folded weights, unfolded onto (W, gamma, beta)
         t_off = _table(dev, ("src", tgt, R * d), lambda: [s * R * d for s in tgt])
@@ -600,7 +610,8 @@ def _channel_sums(dz, W, idx, Cn, R, d):
     dev = dz.device
     dx = torch.empty((Cn, R, d), dtype=torch.float32, device=dev)
     if N == Cn and tuple(idx) == tuple(range(N)):
-        _gemm(A=dz, B=W, C=dx, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d)
+        _gemm(A=dz, B=W, C=dx, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d,
+              precision=GRAD_PRECISION)
         return dx
     blocks = [[g for g in range(N) if idx[g] == c] for c in range(Cn)]
     per = len(blocks[0])
@@ -609,10 +620,11 @@ def _channel_sums(dz, W, idx, Cn, R, d):
         a_seg = _table(dev, ("aseg", tuple(idx), Cn, R * d), lambda: [g * R * d for b in blocks for g in b])
         b_seg = _table(dev, ("bseg", tuple(idx), Cn, d * d), lambda: [g * d * d for b in blocks for g in b])
         _gemm(A=dz, B=W, C=dx, M=R, N=d, K=per * d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=Cn, c_batch=R * d, k_seg=d, a_seg_off=a_seg,
-              b_seg_off=b_seg, precision=0)
+              b_seg_off=b_seg, precision=GRAD_PRECISION)
         return dx
     part = torch.empty((N, R, d), dtype=torch.float32, device=dev)
-    _gemm(A=dz, B=W, C=part, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d)
+    _gemm(A=dz, B=W, C=part, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=N, a_batch=R * d, b_batch=d * d, c_batch=R * d,
+          precision=GRAD_PRECISION)
     srct = _table32(dev, ("idx32", tuple(idx)), lambda: list(idx))
     _lib.check(_lib.lib().as_group_reduce(_lib.ptr(part), _lib.ptr(srct), N, Cn, R * d, _lib.ptr(dx), _lib.stream_ptr()), "as_group_reduce")
     return dx

@@ -190,6 +190,8 @@ int as_gru_bidir_bwd(const float* dy, const float* y, const float* gates, const 
 /* Bidirectional LSTM layer, forward / backward (nn.LSTM semantics; the RNNType.LSTM switch of
  * phoneme_to_articulation/__init__.py:47-49 used by principal_components/models/rnn.py:58-68).  Packed-sequence
  * semantics as as_gru_bidir_fwd; gate row order i, f, g, o; h0 = c0 = 0.
+ *   H     : 32, 64, 128 run register-resident kernels; any other multiple of 4 (up to 1636 with a backward) the plain
+ *           kernels (W_hh streamed from L2 every step; several times slower per step), else AS_ERR_UNSUPPORTED
  *   gi    : W_ih x + b_ih, [B*T][2][4H], or (tokens != NULL) a table [V][2][4H] indexed by tokens[b*tok_stride + t]
  *   w_hh  : [2][4H][H], b_hh : [2][4H];  y : [B][T][2H]
  *   gates : NULL (inference) or [B][T][2][5][H] receiving i, f, g, o, c for the backward

@@ -257,12 +257,14 @@ def test_gemm_batched_strided_and_shift(dev):
                      rtol=2e-5, atol=1e-4, what=f"batched shift, direction {d}")
 
 
+@pytest.mark.parametrize("prec", [0, 3], ids=["exact", "lib"])
 @pytest.mark.parametrize("R,d,G,big", [(200, 64, 6, False), (1500, 256, 12, False), (77, 32, 3, False), (6400, 256, 6, True)])
-def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
+def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big, prec):
     """as_gemm.res / .relu_bits / .mask_bits / .k_seg (the fused pieces of a ChannelProcessingLayer group,
     transformer/models.py:70-100 and its autograd): out-projection + residual written into the concatenated layout; a ReLU's
     bit image; in-projection input gradient + residual gradient through that mask; per-channel input gradients summed
-    over the blocks of a channel by ONE segmented GEMM."""
+    over the blocks of a channel by ONE segmented GEMM.  `lib`: as_gemm.precision = 3, the same calls in the library's matrix
+    arithmetic (gemm_s6.hip: both operand orientations, the same extended operands), same bounds."""
     from artspeech_amd import _lib
     L = _lib.lib()
     rng = np.random.RandomState(R + d + G)
@@ -277,6 +279,7 @@ def test_gemm_residual_mask_and_segmented_reduction(dev, R, d, G, big):
     def call(**kw):
         g = _lib.Gemm()
         g.batch = 1
+        g.precision = prec
         for k, v in kw.items():
             setattr(g, k, v.data_ptr() if torch.is_tensor(v) else v)
         _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")

@@ -67,6 +67,19 @@ def test_random_configurations_vs_oracle(seed, dev):
     (principal_components/models/rnn.py:58-109)."""
     r = np.random.RandomState(700 + seed)
     lstm, H, E, V = bool(r.randint(0, 2)), int(r.choice([32, 64, 128])), int(r.choice([8, 20, 64, 100])), int(r.randint(2, 60))
+    _check_configuration(r, seed, lstm, H, E, V, dev)
+
+
+@pytest.mark.parametrize("lstm", [True, False], ids=["lstm", "gru"])
+@pytest.mark.parametrize("H", [20, 100, 260])
+def test_any_hidden_size_vs_oracle(lstm, H, dev):
+    """Hidden sizes outside {32, 64, 128} (nn.LSTM / nn.GRU take any): the plain recurrence kernels (lstm.hip / gru.hip,
+    `*_generic_kernel`), forward and backward, against the same oracle and the same bounds."""
+    r = np.random.RandomState(900 + H + int(lstm))
+    _check_configuration(r, H, lstm, H, int(r.choice([8, 64])), int(r.randint(2, 60)), dev)
+
+
+def _check_configuration(r, seed, lstm, H, E, V, dev):
     names = ["tongue", "lower-lip", "pharynx", "upper-lip"][:int(r.randint(1, 5))]
     comps = {n: int(r.randint(1, 13)) for n in names}
     B, T = int(r.randint(1, 8)), int(r.randint(1, 61))

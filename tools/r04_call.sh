@@ -1,9 +1,16 @@
 #!/bin/bash
-. tools/gpu_steps.sh
-O=gpurun_out/r04a; mkdir -p $O
-step 1000 $O/gpu_tests.log python -m pytest tests -x -q -m gpu
-tail -3 $O/gpu_tests.log
-step 400 $O/tbench.log python tools/bench_transformer.py 32 200 3
-grep -v amdgpu.ids $O/tbench.log | tail -4
-ARTSPEECH_MATRIX_ARITH=fp32 step 400 $O/tbench_fp32.log python tools/bench_transformer.py 32 200 3
-grep -v amdgpu.ids $O/tbench_fp32.log | tail -3
+# scratch: one gpurun call of round 4
+source $GRAFT_REPO_ROOT/tools/gpu_steps.sh
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+step 400 $O/t_pc.log python -m pytest tests/test_gpu_principal_components.py -x -q
+tail -5 $O/t_pc.log
+step 300 $O/bt_lib.log python tools/bench_transformer.py 32 200 4
+grep "fwd+bwd" $O/bt_lib.log
+export ARTSPEECH_GRAD_PRECISION=f32
+step 300 $O/bt_f32.log python tools/bench_transformer.py 32 200 4
+grep "fwd+bwd" $O/bt_f32.log
+export ARTSPEECH_GRAD_PRECISION=lib
+export ARTSPEECH_GEMM_PRECISION=lib
+step 300 $O/bt_all.log python tools/bench_transformer.py 32 200 4
+grep "fwd+bwd" $O/bt_all.log
