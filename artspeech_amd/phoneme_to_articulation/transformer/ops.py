@@ -29,7 +29,7 @@ GEMM_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GEMM_PRECISION", "f32")]
 
 
 # Precision of the INPUT-GRADIENT GEMMs (dx = dz W, with their residual / ReLU-mask / segmented-reduction operands): the library's
-# matrix arithmetic by default.  Gradients are held to the oracle by a yardstick relative to their own magnitude and the split
+# matrix arithmetic by default.  The parity tests hold gradients to a yardstick relative to their own magnitude and the split
 # product is at least as accurate as the fp32 instruction's (tests/test_gpu_parity.py::test_split_matrix_arithmetic_error_vs_fp64),
 # so nothing a forward value is compared with depends on this.  ARTSPEECH_GRAD_PRECISION=f32 keeps them on the fp32 instruction.
 GRAD_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GRAD_PRECISION", "lib")]
