@@ -30,6 +30,10 @@ struct GemmK {
     // split-K: blockIdx.y owns reduction range [y*kchunk, (y+1)*kchunk); partial tiles go to a dense slab
     // [split][batch][M][N + has_colsum]; a second kernel sums the slabs in a fixed order (deterministic).
     int splitk, kchunk, batch;
+    // split-K with splitk % 8 == 0: all output tiles of one reduction chunk go to ONE XCD (workgroup w runs on XCD w % 8, each
+    // XCD has its own L2): the chunk's operand panels are then fetched from memory once and shared by its tiles, instead of
+    // (nearly) once per XCD -- the three GRU-side weight gradients of the BiGRU step: 100 -> 3x MB per launch (PMC)
+    int xcd_chunks;
     float* slab;
     // optional arrival counters, one per (batch, output tile), zero between launches: the workgroup that delivers the last
     // partial of a tile sums the slabs itself (fixed k order) and runs the ordinary epilogue -- no second kernel
@@ -199,7 +203,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
         x.bz = (int)(w / per_batch);
         const int wrem = (int)(w - x.bz * per_batch);
         x.ks = wrem / per_split;
-        const int xy = wrem - x.ks * per_split;
+        int xy = wrem - x.ks * per_split;
+        if (!EXT && g.xcd_chunks) {   // chunk = XCD + 8 * round, tile = position inside the XCD's share of the work list
+            const int q = wrem >> 3, rnd = q / per_split;
+            x.ks = (wrem & 7) + 8 * rnd;
+            xy = q - rnd * per_split;
+        }
         x.xy = xy;
         x.tn_idx = xy / tiles_m;
         if constexpr (EXT) {
@@ -808,7 +817,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.a_vec = aligned16(g->A) && a_ld % 4 == 0 && g->a_batch % 4 == 0;
     k.b_vec = aligned16(g->B) && b_ld % 4 == 0 && g->b_batch % 4 == 0;
     hipStream_t st = (hipStream_t)stream;
-    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr; k.counters = nullptr;
+    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr; k.counters = nullptr; k.xcd_chunks = 0;
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
     k.bias_off = (const long*)g->bias_off;
@@ -913,9 +922,16 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
         if (sk > 64) sk = 64;
         const long per = (long)g->batch * g->M * (g->N + (g->colsum ? 1 : 0));
         if (sk * per > g->splitk_ws_floats) sk = g->splitk_ws_floats / per;
+        // weight-gradient shapes with many tiles per chunk: a multiple of 8 chunks, one XCD per chunk (GemmK::xcd_chunks)
+        static const bool no_xcd = AS_DIAG_SET("AS_NO_XCD_CHUNKS");
+        const bool want_xcd = !a_kc && !b_kc && sk >= 12 && tiles >= 16 && !no_xcd;
+        if (want_xcd)   // the nearest multiple of 8 (downwards) whose BK-rounded chunks still number a multiple of 8
+            for (long c = (sk + 4) / 8 * 8; c >= 8; c -= 8)
+                if (as_cdiv(g->K, as_round_up(as_cdiv(g->K, c), BK)) % 8 == 0) { sk = c; break; }
         if (sk > 1) {
             k.kchunk = (int)as_round_up(as_cdiv(g->K, sk), BK);
             k.splitk = as_cdiv(g->K, k.kchunk);
+            k.xcd_chunks = want_xcd && k.splitk % 8 == 0;
             k.slab = g->splitk_ws;
             // few slabs: the last workgroup to arrive at a tile sums them in the kernel (input gradient of GRU layer 1, 3 slabs:
             // 52 us against 36 + 45 for a reduce kernel that has to squeeze in beside the side stream's persistent GEMM).
