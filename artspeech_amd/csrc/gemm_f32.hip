@@ -804,6 +804,12 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     const bool a_kc = g->a_k == 1 && !(g->a_i == 1 && g->colsum), b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
     if (!a_kc && !b_kc && g->k_tri == 0) {  // weight-gradient shapes: the kernel of wgrad_f32.hip (it does not know k_tri)
+        // precision == 3 in the split arithmetic: few, long reductions over 128 x 128 tiles staged once per workgroup (gemm_s6.hip;
+        // the transformer's grouped weight gradients, 110 x [256 x 256 x 6400]: 741 -> 4xx us)
+        if (g->precision == 3 && g->a_i == 1 && g->b_j == 1) {
+            const int took = as_gemm_s6_nt_ext(g, (hipStream_t)stream);
+            if (took != 0) return took < 0 ? took : 0;
+        }
         const int taken = as_wgrad_try(g, (hipStream_t)stream);
         if (taken != 0) return taken < 0 ? taken : 0;
     }

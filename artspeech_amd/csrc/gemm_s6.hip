@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -46,6 +47,8 @@ struct S6K {
     const float* res; long res_ld, res_batch; const long* res_off;
     const unsigned* mask_bits; long mask_batch;
     int k_seg, nseg; const long* a_seg_off; const long* b_seg_off;
+    float* colsum; long colsum_batch;      // A column-contiguous only: colsum[g][m] = sum_k A[g][k][m]
+    int xcd_group, batch;                  // > 0: tiles per batch member, all on one XCD (see the kernel)
 };
 
 typedef const __attribute__((address_space(1))) char* gptr;
@@ -59,20 +62,42 @@ __device__ __forceinline__ gptr uniform_ptr(const void* p) {   // see lin_f32.hi
 // BNC: the B operand is column-contiguous in memory, B[k][n] (an input gradient dx = dz . W with W as the forward stores it):
 // a thread then loads 8 consecutive k of ONE column (8 dword loads, each coalesced over the 64 columns of its wave) and writes
 // 16 bytes per plane.  EXT: res / mask_bits / k_seg.
-template <bool BNC, bool EXT>
+template <bool ANC, bool BNC, bool EXT>
 __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * BUF];
-    // block -> (batch, n-tile, m-tile): the m-tiles of one (batch, n-tile) are consecutive (they share the B panel in L2)
+    // block -> (batch member, m-tile, n-tile), XCD-aware (workgroup w runs on XCD w % 8, each XCD has its own L2)
     int t = blockIdx.x;
-    const int tm = t % g.tiles_m;
-    t /= g.tiles_m;
-    const int tn = t % g.tiles_n, bz = t / g.tiles_n;
+    int tm, tn, bz;
+    if (g.xcd_group > 0) {
+        // long reductions over few tiles (weight gradients): the tiles of one batch member read the same two operand panels from
+        // HBM.  Workgroup w runs on XCD w % 8 and every XCD has its own L2: all tiles of a member go to ONE XCD, next to each
+        // other in its dispatch order (member = XCD + 8 * round), so that each panel is fetched once instead of once per tile
+        // column / row (110 x [256 x 256 x 6400]: 2.9 -> 1.4 GB per launch).
+        const int q = t >> 3, rnd = q / g.xcd_group;
+        const int member = (t & 7) + 8 * rnd;
+        if (member >= g.batch) return;
+        t = q - rnd * g.xcd_group;
+        tm = t % g.tiles_m;
+        tn = t / g.tiles_m;
+        bz = member;
+    } else if (g.tiles_n > 1) {
+        // the n-tiles of one 128-row panel of A (activations, streamed from HBM; B = a weight matrix that stays in L2) on one XCD,
+        // next to each other: panel = XCD + 8 * round
+        const int q = t >> 3, rnd = q / g.tiles_n;
+        const int panel = (t & 7) + 8 * rnd;
+        if (panel >= g.batch * g.tiles_m) return;
+        tn = q - rnd * g.tiles_n;
+        tm = panel % g.tiles_m;
+        bz = panel / g.tiles_m;
+    } else {
+        tm = t % g.tiles_m;
+        tn = 0;
+        bz = t / g.tiles_m;
+    }
     const int m0 = tm * TB, n0 = tn * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // loads: thread -> rows (tid >> 2) and (tid >> 2) + 64 of each operand tile, 16-byte chunk tid & 3 of the row's 16 k
-    const int lrow = tid >> 2, lch = tid & 3;
     const bool seg = EXT && g.k_seg > 0;
     const long* a_seg = seg ? g.a_seg_off + (long)bz * g.nseg : nullptr;
     const long* b_seg = seg ? g.b_seg_off + (long)bz * g.nseg : nullptr;
@@ -80,39 +105,59 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     gptr Bu = uniform_ptr(g.B + (seg ? b_seg[0] : g.b_off ? g.b_off[bz] : (long)bz * g.b_batch));
     // the NEXT segment's bases are fetched a segment ahead (scalar loads that have 16 k-tiles to arrive)
     long a_next = seg ? a_seg[min(1, g.nseg - 1)] : 0, b_next = seg ? b_seg[min(1, g.nseg - 1)] : 0;
-    unsigned a_off[2], b_off[2];
-    int wr[2];
+    // An operand tile is 128 rows (m or n) x 16 k.  Reduction-contiguous operand: thread -> rows (tid >> 2) and (tid >> 2) + 64,
+    // 16-byte chunk tid & 3 of the row's 16 k (two dwordx4 loads, 3 x 8-byte LDS writes each) into a [row][16 k] image that
+    // ds_read_b128 reads.  Row-contiguous operand (X[k][row]): two dwordx4 loads of 4 consecutive rows at one k each (a wave
+    // reads 2 x 512 consecutive bytes), the same 3 x 8-byte writes into a [k][128 rows] image, and the fragment (8 consecutive k
+    // of the lane's row) comes out of two ds_read_b64_tr_b16, gfx950's transposing LDS read.  (The first form of this path
+    // loaded 8 dwords of consecutive k per thread: one vector-memory instruction per 256 bytes made the texture addresser the
+    // bound -- 110 x [256 x 256 x 6400] weight gradients: 692 us.)
+    struct Lay { unsigned off[2]; int wr[2]; unsigned ld4; };
+    auto layout = [&](bool nc, int r0, int rows, long ld) {
+        Lay y;
+        if (!nc) {
+            const int lrow = tid >> 2, lch = tid & 3;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = lrow + 64 * q;
-        a_off[q] = (unsigned)((long)min(m0 + r, g.M - 1) * g.lda + lch * 4) * 4u;    // bytes (operands < 4 GB: host check)
-        b_off[q] = (unsigned)((long)min(n0 + r, g.N - 1) * g.ldb + lch * 4) * 4u;
-        wr[q] = r * 32 + (((lch >> 1) ^ ((r >> 3) & 1)) * 16) + (lch & 1) * 8;
-    }
-    // BNC: column n0 + (tid & 127), k half tid >> 7 (8 consecutive k); byte step between two k = 4 * ldb
-    const int bn = tid & 127, bkh = tid >> 7;
-    const unsigned ldb4 = (unsigned)g.ldb * 4u;
-    const unsigned bnc_off = (unsigned)min(n0 + bn, g.N - 1) * 4u + (unsigned)(bkh * 8) * ldb4;
-    const int bnc_wr = bn * 32 + ((bkh ^ ((bn >> 3) & 1)) * 16);
+            for (int q = 0; q < 2; ++q) {
+                const int r = lrow + 64 * q;
+                y.off[q] = (unsigned)((long)min(r0 + r, rows - 1) * ld + lch * 4) * 4u;    // bytes (operands < 4 GB: host check)
+                y.wr[q] = r * 32 + (((lch >> 1) ^ ((r >> 3) & 1)) * 16) + (lch & 1) * 8;
+            }
+            y.ld4 = 4u;                                     // byte step per k
+        } else {
+            // k-major image [16 k][128 rows] per plane (256-byte image rows, 16-byte chunks XOR-swizzled: image (b) of the
+            // guide's T10): thread -> k = tid / 32 (+ 8), rows 4 (tid % 32) .. + 3
+            const int c4 = tid & 31, kq = tid >> 5;
+            y.ld4 = (unsigned)ld * 4u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int kk = kq + 8 * q;
+                y.off[q] = (unsigned)min(r0 + 4 * c4, rows - 4) * 4u + (unsigned)kk * y.ld4;
+                y.wr[q] = 256 * kk + 16 * ((c4 >> 1) ^ (((kk & 3) << 2) | ((kk >> 2) & 3))) + 8 * (c4 & 1);
+            }
+        }
+        return y;
+    };
+    const Lay la = layout(ANC, m0, g.M, g.lda), lb = layout(BNC, n0, g.N, g.ldb);
     const int nk = g.K / BK;
     const int kspan = seg ? g.k_seg : g.K;     // k range addressed from the current bases
     int ld_t = 0, ld_k = 0, ld_seg = 0;        // the next load: k-tile, k inside the segment, segment (all wave-uniform)
     struct Regs { f32x4 a[2], b[2]; };
-    auto load = [&](Regs& x) {
-        const unsigned ko = (unsigned)ld_k * 4u;
+    auto load_op = [&](auto ncc, f32x4 (&v)[2], gptr base, const Lay& y) {
+        const unsigned ko = (unsigned)ld_k * y.ld4;
+        if constexpr (!decltype(ncc)::value) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) x.a[q] = *reinterpret_cast<gptr_f4>(Au + (a_off[q] + ko));
-        if constexpr (!BNC) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) x.b[q] = *reinterpret_cast<gptr_f4>(Bu + (b_off[q] + ko));
+            for (int q = 0; q < 2; ++q) v[q] = *reinterpret_cast<gptr_f4>(base + (y.off[q] + ko));
         } else {
-            const unsigned kb = bnc_off + (unsigned)ld_k * ldb4;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    x.b[q][e] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(Bu + (kb + (unsigned)(q * 4 + e) * ldb4));
+            for (int q = 0; q < 2; ++q) v[q] = *reinterpret_cast<gptr_f4>(base + (y.off[q] + ko));
         }
+    };
+    auto load = [&](Regs& x) {
+#if !defined(AS_S6G_ABL) || AS_S6G_ABL != 1     // ablation 1 (diagnostic builds): no global loads
+        load_op(IC2<ANC>{}, x.a, Au, la);
+        load_op(IC2<BNC>{}, x.b, Bu, lb);
+#endif
         // advance (behind the last tile the loads repeat it: unconditional loads keep hipcc's vmcnt counts exact)
         if constexpr (!EXT) {
             ld_t = min(ld_t + 1, nk - 1);
@@ -131,47 +176,28 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
             }
         }
     };
-    auto store = [&](const Regs& x, int buf) {
-        unsigned char* base = sm + buf * BUF;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};   // ANC with g.colsum: this thread's share of the column sums of A (its 4 columns, its 2 of every 16 k)
+    auto store_op = [&](const f32x4 (&v)[2], unsigned char* base, const Lay& y) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const f32x4 v = x.a[q];
             unsigned h0, m0_, l0, h1, m1, l1;
-            split_pair(v.x, v.y, h0, m0_, l0);
-            split_pair(v.z, v.w, h1, m1, l1);
-            unsigned char* d = base + wr[q];
+            split_pair(v[q].x, v[q].y, h0, m0_, l0);
+            split_pair(v[q].z, v[q].w, h1, m1, l1);
+            unsigned char* d = base + y.wr[q];
             *reinterpret_cast<u32x2*>(d) = (u32x2){h0, h1};
             *reinterpret_cast<u32x2*>(d + PLANE) = (u32x2){m0_, m1};
             *reinterpret_cast<u32x2*>(d + 2 * PLANE) = (u32x2){l0, l1};
         }
-        if constexpr (!BNC) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 v = x.b[q];
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split_pair(v.x, v.y, h0, m0_, l0);
-                split_pair(v.z, v.w, h1, m1, l1);
-                unsigned char* d = base + OPER + wr[q];
-                *reinterpret_cast<u32x2*>(d) = (u32x2){h0, h1};
-                *reinterpret_cast<u32x2*>(d + PLANE) = (u32x2){m0_, m1};
-                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = (u32x2){l0, l1};
-            }
-        } else {
-            u32x4 h, m, l;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split_pair(x.b[q].x, x.b[q].y, h0, m0_, l0);
-                split_pair(x.b[q].z, x.b[q].w, h1, m1, l1);
-                h[2 * q] = h0; h[2 * q + 1] = h1;
-                m[2 * q] = m0_; m[2 * q + 1] = m1;
-                l[2 * q] = l0; l[2 * q + 1] = l1;
-            }
-            unsigned char* d = base + OPER + bnc_wr;
-            *reinterpret_cast<u32x4*>(d) = h;
-            *reinterpret_cast<u32x4*>(d + PLANE) = m;
-            *reinterpret_cast<u32x4*>(d + 2 * PLANE) = l;
+    };
+    int st_t = 0;       // k-tile the next store() holds (behind the last one the stores repeat it)
+    auto store = [&](const Regs& x, int buf) {
+        unsigned char* base = sm + buf * BUF;
+        if constexpr (ANC) {
+            if (g.colsum && st_t < nk) csum += x.a[0] + x.a[1];
+            ++st_t;
         }
+        store_op(x.a, base, la);
+        store_op(x.b, base + OPER, lb);
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -183,6 +209,30 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     const int fsw = ((l31 >> 3) & 1) ^ lh;     // 16-byte half of this lane's 8 k inside its (swizzled) row
     const unsigned char* a_rd = sm + (wm * 64 + l31) * 32 + fsw * 16;
     const unsigned char* b_rd = sm + OPER + (wn * 64 + l31) * 32 + fsw * 16;
+    // k-major images: lane 4q + p of a 16-lane group addresses row (= k) 8 lh + 4 jj + q, image columns 4p .. 4p + 3 of the group's 16
+    // (ds_read_b64_tr_b16 hands lane i of the group column i of the four rows)
+    typedef __attribute__((address_space(3))) s16x4* lds_tr;
+    unsigned tr_a[2][2], tr_b[2][2];
+    {
+        const int p = lane & 3, q = (lane >> 2) & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int row = 8 * lh + 4 * jj + q;
+                const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+                const int ca = wm * 64 + i * 32 + g1 * 16 + 4 * p, cb = wn * 64 + i * 32 + g1 * 16 + 4 * p;
+                tr_a[i][jj] = 256 * row + 16 * ((ca >> 3) ^ sw) + 8 * ((ca >> 2) & 1);
+                tr_b[i][jj] = OPER + 256 * row + 16 * ((cb >> 3) ^ sw) + 8 * ((cb >> 2) & 1);
+            }
+    }
+    auto frag_tr = [&](unsigned o0, unsigned o1, int imm) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(sm + o0 + imm));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(sm + o1 + imm));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
 
     Regs x[2];
     load(x[0]);
@@ -214,8 +264,15 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+#if defined(AS_S6G_ABL) && AS_S6G_ABL == 2      // ablation 2: plain 16-byte reads in place of the transposing ones (wrong numbers)
                 fa[i][p] = *reinterpret_cast<const bf16x8*>(a_rd + U * BUF + p * PLANE + i * 32 * 32);
                 fb[i][p] = *reinterpret_cast<const bf16x8*>(b_rd + U * BUF + p * PLANE + i * 32 * 32);
+                continue;
+#endif
+                if constexpr (ANC) fa[i][p] = frag_tr(tr_a[i][0], tr_a[i][1], U * BUF + p * PLANE);
+                else fa[i][p] = *reinterpret_cast<const bf16x8*>(a_rd + U * BUF + p * PLANE + i * 32 * 32);
+                if constexpr (BNC) fb[i][p] = frag_tr(tr_b[i][0], tr_b[i][1], U * BUF + p * PLANE);
+                else fb[i][p] = *reinterpret_cast<const bf16x8*>(b_rd + U * BUF + p * PLANE + i * 32 * 32);
             }
         constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {0, 1, 2, 0, 1, 0};   // without mid.lo, lo.mid, lo.lo
 #pragma unroll
@@ -225,7 +282,9 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[o]], fb[j][PB[o]], acc[i][j], 0, 0, 0);
+#if !defined(AS_S6G_ABL) || AS_S6G_ABL != 3     // ablation 3: no split + LDS writes
         store(x[U ^ 1], U ^ 1);   // (behind the last tile: a clamped repeat into the idle buffer)
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -236,6 +295,21 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     }
     if (kt < nk) tile(IC2<0>{});
 
+    if constexpr (ANC) {   // column sums of A (a bias gradient): the two k halves of a column meet in LDS, in a fixed order
+        if (g.colsum && tn == 0) {
+            f32x4* cs = reinterpret_cast<f32x4*>(sm);        // [8 k groups][32 column quads]
+            cs[tid] = csum;
+            __syncthreads();
+            if (tid < TB) {
+                const float* c1 = reinterpret_cast<const float*>(sm);
+                float t8 = 0.f;
+#pragma unroll
+                for (int kq = 0; kq < 8; ++kq) t8 += c1[kq * TB + tid];
+                // (a clamped quad -- M % 128 != 0 -- repeats valid columns at the tile's end: those lanes hold other columns' sums)
+                if (m0 + tid < g.M && (m0 + (tid & ~3) + 4 <= g.M)) g.colsum[(long)bz * g.colsum_batch + m0 + tid] = t8;
+            }
+        }
+    }
     // ---- epilogue: D[i][j] block (i, j) of the wave: row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = n0 + wn * 64 + j * 32 + l31
     float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
     const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
@@ -298,19 +372,25 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
 // see gemm_internal.h
 int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st) {
     if (as_matrix_arith() != AS_ARITH_BF16X6) return 0;
-    const bool bnc = g->b_k != 1;     // B[k][n], n contiguous (input-gradient orientation)
-    if (g->a_k != 1 || (bnc && g->b_j != 1) || g->K < BK || g->K % BK || g->act < 0 || g->act > 2) return 0;
-    if (g->k_tri || g->colsum || g->splitk_ws || g->accumulate || g->b_kT || g->b_kshift || (g->precision != 0 && g->precision != 3)) return 0;
+    const bool anc = g->a_k != 1;     // A[k][m], m contiguous (weight-gradient orientation)
+    const bool bnc = g->b_k != 1;     // B[k][n], n contiguous (input- and weight-gradient orientation)
+    if ((anc && (g->a_i != 1 || !bnc)) || (bnc && g->b_j != 1) || g->K < BK || g->K % BK || g->act < 0 || g->act > 2) return 0;
+    if (g->k_tri || g->accumulate || g->b_kT || g->b_kshift || (g->precision != 0 && g->precision != 3)) return 0;
+    if (g->colsum && !anc) return 0;
     const bool ext = g->res || g->mask_bits || g->k_seg;
+    if (anc && (ext || g->relu_bits || g->bias)) return 0;
     if (g->relu_bits && (g->act != 1 || ext)) return 0;
-    if (g->a_i % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (!g->a_off && !g->k_seg && g->a_batch % 4)) return 0;
+    if (!anc && (g->a_i % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (!g->a_off && !g->k_seg && g->a_batch % 4))) return 0;
     if (!bnc && (g->b_j % 4 || (reinterpret_cast<uintptr_t>(g->B) & 15) || (!g->b_off && !g->k_seg && g->b_batch % 4))) return 0;
+    // row-contiguous operands are loaded as float4s along the rows
+    if (anc && (g->a_k % 4 || g->M % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (!g->a_off && g->a_batch % 4))) return 0;
+    if (bnc && (g->b_k % 4 || g->N % 4 || (reinterpret_cast<uintptr_t>(g->B) & 15) || (!g->b_off && !g->k_seg && g->b_batch % 4))) return 0;
     if (g->k_seg && (g->k_seg % BK || g->K % g->k_seg || !g->a_seg_off || !g->b_seg_off)) return 0;
     const long kspan = g->k_seg ? g->k_seg : g->K;
     // 32-bit byte offsets inside one batch member / segment
-    if ((long)g->M * g->a_i >= (1L << 30) || (bnc ? kspan * g->b_k + g->N : (long)g->N * g->b_j) >= (1L << 30)) return 0;
+    if ((anc ? kspan * g->a_k + g->M : (long)g->M * g->a_i) >= (1L << 30) || (bnc ? kspan * g->b_k + g->N : (long)g->N * g->b_j) >= (1L << 30)) return 0;
     S6K k{};
-    k.A = g->A; k.lda = g->a_i; k.a_batch = g->a_batch;
+    k.A = g->A; k.lda = anc ? g->a_k : g->a_i; k.a_batch = g->a_batch;
     k.B = g->B; k.ldb = bnc ? g->b_k : g->b_j; k.b_batch = g->b_batch;
     k.C = g->C; k.ldc = g->ldc; k.c_batch = g->c_batch;
     k.bias = g->bias; k.bias_batch = g->bias_batch;
@@ -321,15 +401,26 @@ int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st) {
     k.mask_bits = g->mask_bits; k.mask_batch = g->mask_batch;
     k.k_seg = g->k_seg; k.nseg = g->k_seg ? g->K / g->k_seg : 1;
     k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
-    const long blocks = (long)k.tiles_m * k.tiles_n * g->batch;
+    k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
+    long blocks = (long)k.tiles_m * k.tiles_n * g->batch;
     if (blocks > (1L << 30)) return 0;
+    k.batch = g->batch;
+    if (anc) {
+        // one workgroup walks the whole reduction of its tile: worth it once the tiles fill the chip (else wgrad_f32.hip's stream-K)
+        if (blocks < 256 && !AS_DIAG_SET("AS_S6_TN_ANY")) return 0;
+        k.xcd_group = k.tiles_m * k.tiles_n;
+        blocks = (long)as_round_up(g->batch, 8) * k.xcd_group;
+    } else if (k.tiles_n > 1) {
+        blocks = (long)as_round_up((long)g->batch * k.tiles_m, 8) * k.tiles_n;
+    }
     const dim3 grid((unsigned)blocks), blk(NTH);
-    if (ext) {
-        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<true, true>), grid, blk, 0, st, k);
-        else hipLaunchKernelGGL((gemm_s6_kernel<false, true>), grid, blk, 0, st, k);
+    if (anc) hipLaunchKernelGGL((gemm_s6_kernel<true, true, false>), grid, blk, 0, st, k);
+    else if (ext) {
+        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<false, true, true>), grid, blk, 0, st, k);
+        else hipLaunchKernelGGL((gemm_s6_kernel<false, false, true>), grid, blk, 0, st, k);
     } else {
-        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<true, false>), grid, blk, 0, st, k);
-        else hipLaunchKernelGGL((gemm_s6_kernel<false, false>), grid, blk, 0, st, k);
+        if (bnc) hipLaunchKernelGGL((gemm_s6_kernel<false, true, false>), grid, blk, 0, st, k);
+        else hipLaunchKernelGGL((gemm_s6_kernel<false, false, false>), grid, blk, 0, st, k);
     }
     AS_LAUNCH_CHECK("as_gemm_s6");
     return 1;

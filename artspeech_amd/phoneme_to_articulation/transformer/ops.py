@@ -236,7 +236,7 @@ class GroupedLinear(torch.autograd.Function):
             dW = torch.empty_like(W)
             db = torch.empty((G, N), dtype=torch.float32, device=x.device)
             kw = dict(A=dz, B=x, C=dW, M=N, N=K, K=R, a_i=1, a_k=N, b_j=1, b_k=K, ldc=K, batch=G, a_batch=R * N, c_batch=N * K,
-                      colsum=db, colsum_batch=N)
+                      colsum=db, colsum_batch=N, precision=GRAD_PRECISION)
             if identity:
                 slab = _slab(x.device)
                 kw.update(b_batch=R * K, splitk_ws=slab, splitk_ws_floats=slab.numel())
@@ -565,7 +565,7 @@ class ChannelBlocks(torch.autograd.Function):
               precision=GRAD_PRECISION, **a_lay)
         do_w, do_b = new(G, d, d), new(G, d)
         _gemm(A=dout, B=att, C=do_w, M=d, N=d, K=R, a_i=1, a_k=ldo, b_j=1, b_k=d, ldc=d, batch=G, b_batch=R * d, c_batch=d * d,
-              colsum=do_b, colsum_batch=d, **a_lay, **ws)
+              colsum=do_b, colsum_batch=d, precision=GRAD_PRECISION, **a_lay, **ws)
         # ---- attention core
         dp2 = new(3, G, R, d) if same else None
         dq2 = dp2[0] if same else new(G, R, d)
@@ -577,7 +577,7 @@ class ChannelBlocks(torch.autograd.Function):
         din_w, din_b = new(G, 3 * d, d), new(G, 3 * d)
         for j, (dz, y, rows) in enumerate(((dq2, q, R), (dkv2[0], kv[0], Rs), (dkv2[1], kv[1], Rs))):
             _gemm(A=dz, B=y, C=_ptr(din_w, j * d * d), M=d, N=d, K=rows, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=G, a_batch=rows * d,
-                  b_batch=rows * d, c_batch=3 * d * d, colsum=_ptr(din_b, j * d), colsum_batch=3 * d, **ws)
+                  b_batch=rows * d, c_batch=3 * d * d, colsum=_ptr(din_b, j * d), colsum_batch=3 * d, precision=GRAD_PRECISION, **ws)
         dq, dkv = new(G, R, d), new(2, G, Rs, d)
         w_off = _table(dev, ("inw", G, d), lambda: [g * 3 * d * d + j * d * d for j in range(3) for g in range(G)])
         _gemm(A=dq2, B=in_w, C=dq, M=R, N=d, K=d, a_i=d, a_k=1, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_batch=3 * d * d,
@@ -590,9 +590,9 @@ class ChannelBlocks(torch.autograd.Function):
         s_off2 = _table(dev, ("src2", src, Rs * d), lambda: [s * Rs * d for s in src] * 2)
         dWf, dbf = new(3, G, d, d), new(3, G, d)
         _gemm(A=dq, B=xt, C=dWf, M=d, N=d, K=R, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=G, a_batch=R * d, b_off=t_off, c_batch=d * d,
-              colsum=dbf, colsum_batch=d, **ws)
+              colsum=dbf, colsum_batch=d, precision=GRAD_PRECISION, **ws)
         _gemm(A=dkv, B=xs, C=_ptr(dWf, G * d * d), M=d, N=d, K=Rs, a_i=1, a_k=d, b_j=1, b_k=d, ldc=d, batch=2 * G, a_batch=Rs * d,
-              b_off=s_off2, c_batch=d * d, colsum=_ptr(dbf, G * d), colsum_batch=d, **ws)
+              b_off=s_off2, c_batch=d * d, colsum=_ptr(dbf, G * d), colsum_batch=d, precision=GRAD_PRECISION, **ws)
         dW3, dg3, db3 = new(3, G, d, d), new(3, G, d), new(3, G, d)
         for j, w in enumerate((q_w, k_w, v_w)):
             _lib.check(L.as_unfold_ln(_ptr(dWf, j * G * d * d), _ptr(dbf, j * G * d), _lib.ptr(w), _lib.ptr(ln_w), _lib.ptr(ln_b),

@@ -499,6 +499,45 @@ def test_weight_gradient_stream_k(dev, M, N, K, batch, grouped):
     assert (acc - (c0 + outs[0][0])).abs().max().item() <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("M,N,K,batch,grouped", [(256, 256, 6400, 110, False), (200, 132, 2048, 7, True), (128, 384, 160, 3, False)])
+def test_weight_gradient_split_arithmetic_tiles(dev, M, N, K, batch, grouped):
+    """as_gemm.precision = 3 on a weight-gradient shape (both operands reduction-strided): gemm_s6.hip's kernel with both operand
+    tiles transposed on their way into the plane images, one workgroup per 128 x 128 output tile over the whole reduction, the
+    bias gradient (column sums of A) from the registers the tile loads pass through.  Same bounds as the stream-K kernel's test."""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(M + K + batch)
+    a = rng.randn(batch, K, M).astype(np.float32)
+    b = rng.randn(batch, K, N).astype(np.float32)
+    ad, bd = T_(a, dev), T_(b, dev)
+    perm = rng.permutation(batch)
+    a_off = torch.tensor([int(p) * K * M for p in perm], dtype=torch.int64, device=dev)
+
+    def run():
+        out = torch.full((batch, M, N), float("nan"), device=dev)
+        cs = torch.full((batch, M), float("nan"), device=dev)
+        g = _lib.Gemm()
+        g.A, g.B, g.C = ad.data_ptr(), bd.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.batch = M, N, K, batch
+        g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = 1, M, 1, N, N
+        g.a_batch, g.b_batch, g.c_batch = K * M, K * N, M * N
+        if grouped:
+            g.a_off = a_off.data_ptr()
+        g.colsum, g.colsum_batch = cs.data_ptr(), M
+        g.precision = 3
+        _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+        torch.cuda.synchronize()
+        return out, cs
+
+    outs = [run() for _ in range(3)]
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    aa = a[perm] if grouped else a
+    ref = np.einsum("gkm,gkn->gmn", aa.astype(np.float64), b)
+    scale = np.abs(ref).max()
+    assert np.abs(outs[0][0].cpu().numpy() - ref).max() <= 2e-6 * scale * np.sqrt(K)
+    assert np.abs(outs[0][1].cpu().numpy() - aa.astype(np.float64).sum(1)).max() <= 2e-6 * np.sqrt(K) * np.abs(a).max() * 4
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(384, 128, 6400, 2), (256, 256, 4096, 3), (45, 64, 768, 1), (6400, 256, 768, 1), (100, 256, 2048, 5)])
 def test_gemm_split_k_paths(dev, M, N, K, batch):
     """Long reductions under few output tiles take the split-K paths: slabs summed by the last workgroup to arrive at a tile

@@ -28,14 +28,20 @@ SHAPES = {
     "grub.dw_ih1 768x256": (768, 256, 1, 768, 0, 256, 0, 0, 0, 0),
     "grub.dw_hh 384x128 x2 (shift)": (384, 128, 2, 768, 384, 256, 128, -1, T, 2),
     "transformer dW 256x256 x110": (256, 256, 110, 110 * 256, 256, 110 * 256, 256, 0, 0, 0),
+    # the layout the transformer's modules really use: block-major operands [G][R][256]
+    "transformer dW x110 block-major": (256, 256, 110, 256, R * 256, 256, R * 256, 0, 0, 0),
+    "transformer dW x11 block-major": (256, 256, 11, 256, R * 256, 256, R * 256, 0, 0, 0),
+    "transformer dW x1": (256, 256, 1, 256, 0, 256, 0, 0, 0, 0),
 }
+PREC = int(os.environ.get("AS_BENCH_PRECISION", "0"))   # 3: as_gemm.precision = 3 (gemm_s6.hip's kernel where it takes the shape)
 
 label = "general kernel (AS_NO_WGRAD)" if os.environ.get("AS_NO_WGRAD") else "wgrad_f32_kernel"
 print(f"--- {label}, K = {R}, cu_budget = {cu_budget or 'chip'}, {iters} launches each")
 total_us = 0.0
 for name, (M, N, batch, lda, ab, ldb, bb, ksh, kT, kshb) in SHAPES.items():
-    A = torch.randn(R, lda, device=dev)
-    Bm = torch.randn(R, ldb, device=dev)
+    block_major = ab >= R * M
+    A = torch.randn(batch if block_major else 1, R, lda, device=dev)
+    Bm = torch.randn(batch if block_major else 1, R, ldb, device=dev)
     Cm = torch.empty(batch, M, N, device=dev)
     cs = torch.empty(batch, M, device=dev)
     g = _lib.Gemm()
@@ -47,6 +53,7 @@ for name, (M, N, batch, lda, ab, ldb, bb, ksh, kT, kshb) in SHAPES.items():
     g.splitk_ws, g.splitk_ws_floats = ws.data_ptr(), ws.numel()
     g.colsum, g.colsum_batch = cs.data_ptr(), M
     g.cu_budget = cu_budget
+    g.precision = PREC
     st = _lib.stream_ptr()
     for _ in range(3):
         _lib.check(L.as_gemm_f32(C.byref(g), st))
@@ -61,8 +68,8 @@ for name, (M, N, batch, lda, ab, ldb, bb, ksh, kT, kshb) in SHAPES.items():
     # check against fp64 on a few batch members
     err = 0.0
     for b in sorted({0, batch // 2, batch - 1}):
-        a64 = A[:, b * ab:b * ab + M].double()
-        b64 = Bm[:, b * bb:b * bb + N].double()
+        a64 = (A[b] if block_major else A[0][:, b * ab:b * ab + M]).double()
+        b64 = (Bm[b] if block_major else Bm[0][:, b * bb:b * bb + N]).double()
         if kT:
             s = ksh + b * kshb
             v = b64.reshape(R // kT, kT, N)
