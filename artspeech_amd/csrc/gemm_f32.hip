@@ -32,7 +32,7 @@ struct GemmK {
     int splitk, kchunk, batch;
     // split-K with splitk % 8 == 0: all output tiles of one reduction chunk go to ONE XCD (workgroup w runs on XCD w % 8, each
     // XCD has its own L2): the chunk's operand panels are then fetched from memory once and shared by its tiles, instead of
-    // (nearly) once per XCD -- the three GRU-side weight gradients of the BiGRU step: 100 -> 3x MB per launch (PMC)
+    // (nearly) once per XCD -- the three GRU-side weight gradients of the BiGRU step: 83 -> 32 MB fetched per launch (PMC)
     int xcd_chunks;
     float* slab;
     // optional arrival counters, one per (batch, output tile), zero between launches: the workgroup that delivers the last
@@ -804,8 +804,9 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     const bool a_kc = g->a_k == 1 && !(g->a_i == 1 && g->colsum), b_kc = g->b_k == 1;
     AS_REQUIRE(!(g->b_kT > 0 && b_kc), AS_ERR_BAD_ARG, "as_gemm_f32: b_kshift needs a reduction-strided B operand");
     if (!a_kc && !b_kc && g->k_tri == 0) {  // weight-gradient shapes: the kernel of wgrad_f32.hip (it does not know k_tri)
-        // precision == 3 in the split arithmetic: few, long reductions over 128 x 128 tiles staged once per workgroup (gemm_s6.hip;
-        // the transformer's grouped weight gradients, 110 x [256 x 256 x 6400]: 741 -> 4xx us)
+        // precision == 3 in the split arithmetic: one workgroup per 128 x 128 output tile over the whole reduction, operand tiles
+        // staged once per workgroup (gemm_s6.hip; the transformer's grouped weight gradients, 110 x [256 x 256 x 6400]: 704 us
+        // with the stream-K kernel below, 597 - 659 us there; it declines launches of fewer than 256 tiles)
         if (g->precision == 3 && g->a_i == 1 && g->b_j == 1) {
             const int took = as_gemm_s6_nt_ext(g, (hipStream_t)stream);
             if (took != 0) return took < 0 ? took : 0;

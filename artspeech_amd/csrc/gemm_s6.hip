@@ -1,21 +1,34 @@
-// General "NT" GEMM in the split matrix arithmetic (as_set_matrix_arith(1)):  C[g][M][N] = act(A[g][M][K] . B[g][N][K]^T + bias)
-// with BOTH operands fp32 in memory, reduction-contiguous (an nn.Linear forward: encoder_decoder/models.py:111-116 -- the GRU
-// input projection, the trunk Linear -- and, with a transposed copy of the weights, its input gradient).  Each fp32 operand
-// element is split exactly into three bfloat16 numbers and the product is rebuilt from six plane products on
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (lin_f32.hip has the arithmetic's rationale and its error measurements).
+// General GEMM in the split matrix arithmetic (as_set_matrix_arith(1); as_gemm.precision = 3):  C[g] = epilogue(A[g] . B[g]) with
+// BOTH operands fp32 in memory, each element split exactly into three bfloat16 numbers and the product rebuilt from six plane
+// products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (lin_f32.hip has the arithmetic's rationale and error measurements).
+// Three operand orientations, one kernel:
+//   forward          C[M][N] = act(A[M][K] . B[N][K]^T + bias)     (an nn.Linear: encoder_decoder/models.py:111-116,
+//                    transformer/models.py:47-100), optional ReLU bit image;
+//   input gradient   C[M][N] = keep ? res + A[M][K] . B[K][N] : 0  (dx = dz . W with W as the forward stores it; the residual
+//                    gradient as the accumulators' initial value, the ReLU backward from the bit image, the reduction optionally
+//                    in segments with their own operand bases: as_gemm.res / mask_bits / k_seg);
+//   weight gradient  C[M][N] = A[K][M]^T . B[K][N]                 (dW = dz^T . x, bias gradient = column sums of A fused).
 //
 // Shape of the kernel -- what the measurements of lin_s6_kernel asked for:
 //   * that kernel's loop is bound by the bytes its CUs pull from L2 (a wave streams the weight planes of its own 32 columns:
 //     9.3 B per SIMD-cycle of matrix work at 64 x 256 tiles): here BOTH operands go through LDS, staged once per workgroup,
 //     on square 128 x 128 tiles -- 5.3 B per SIMD-cycle, and no pre-split copy of the weights (no plane-emit launch);
 //   * 4 waves (2 x 2), a wave owns 64 x 64 = four accumulators: a fragment read from LDS feeds two matrix instructions per
-//     plane pair (12 ds_read_b128 per 24 MFMAs and 16-deep k-step);
-//   * every thread loads 4 + 4 consecutive k of two A rows and two B rows per 16-deep k-tile (global_load_dwordx4, two tiles
-//     ahead in two register sets), splits them (4.5 vector instructions per element, each element once per workgroup) and
-//     writes 3 x 8 bytes per load into the tile's plane images ([plane][128 rows][16 k] bf16 = 32-byte rows, the two 16-byte
-//     halves XOR-swizzled by (row >> 3) & 1: the 16 lanes one LDS cycle of a ds_read_b128 serves then cover all 64 banks);
+//     plane pair;
+//   * every thread loads two float4s per operand and 16-deep k-tile (two tiles ahead in two register sets), splits them (4.5
+//     vector instructions per element, each element once per workgroup) and writes 3 x 8 bytes per load into the tile's plane
+//     images.  A reduction-contiguous operand gives a [128 rows][16 k] image (32-byte rows, the two 16-byte halves XOR-swizzled
+//     by (row >> 3) & 1) read with ds_read_b128; a row-contiguous one (X[k][row]) a [16 k][128 rows] image (256-byte rows,
+//     16-byte chunks XOR-swizzled) from which gfx950's transposing read ds_read_b64_tr_b16 delivers the same fragment (8
+//     consecutive k of the lane's row) in two reads -- the loads stay float4s along the contiguous dimension;
 //   * 48 KB of LDS (two tiles) and <= 168 VGPRs: three workgroups per CU, each other's split / barrier / epilogue phases under
-//     each other's matrix work; one barrier per k-tile.
+//     each other's matrix work; one barrier per k-tile;
+//   * XCD-aware tile order: workgroup w runs on XCD w % 8 and each XCD has its own L2, so the tiles that read the same
+//     activation panel (the n-tiles of 128 rows of A; all tiles of a weight-gradient batch member) are numbered onto one XCD,
+//     next to each other -- the panel is fetched from HBM once (PMC: 2.9 -> 1.5 GB for 110 x [256 x 256 x 6400]).
+//   Measured: 51200 x 256 x 256 forward 82.9 (fp32 kernel) -> 56.0 us, 51200 x 1024 x 1024 877 -> 565 us (190 TF/s-equivalent);
+//   the weight-gradient orientation is bound by its operand loads (ablation: 1045 -> 614 us without them at three workgroups
+//   per CU), 155 - 164 TF/s-equivalent.
 #include "gemm_internal.h"
 #include "split_arith.h"
 

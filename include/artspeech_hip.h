@@ -229,11 +229,14 @@ typedef struct as_gemm {
     /* 0: exact fp32 on the f32 MFMA (default).  1 / 2: forward linears (a_k == b_k == 1, float4-clean operands) may run on
        the bf16 MFMA with every fp32 element split on the fly into 2 / 3 bf16 pieces and the product rebuilt from 3 / 6
        cross terms with fp32 accumulation (error ~2^-16 / ~2^-23 of sum |a||b|); other shapes silently stay exact.
-       3: the library's current matrix arithmetic (as_set_matrix_arith): in mode 1 a forward shape (a_k == b_k == 1; plain or
-       relu_bits epilogue; linear or grouped batches; K % 16 == 0, float4-clean operands) runs on the bf16 matrix instruction
-       with both operands split exactly into three planes inside the kernel, whatever its size; anything else, and mode 0,
-       as 0.  The transformer modules opt in with ARTSPEECH_GEMM_PRECISION=lib (forward + backward 218 -> 198 ms at configs[3];
-       the full-width contours then sit at 1.19 x the 1e-4 bound against the reference fixture, 0.89 x with 0: default 0). */
+       3: the library's current matrix arithmetic (as_set_matrix_arith): in mode 1 the shapes gemm_s6.hip's kernel takes run on
+       the bf16 matrix instruction with both operands split exactly into three planes inside the kernel, whatever their size --
+       forward (a_k == b_k == 1; plain or relu_bits epilogue), input gradient (a_k == 1, b_j == 1; with res / mask_bits / k_seg)
+       and weight gradient (a_i == b_j == 1, >= 256 output tiles of 128 x 128; with colsum); linear or grouped batches,
+       K % 16 == 0, float4-clean operands.  Anything else, and mode 0, as 0.  The transformer modules use it for every backward
+       GEMM (ARTSPEECH_GRAD_PRECISION, default "lib": 218 -> 190 ms at configs[3]) and offer it for the forward ones
+       (ARTSPEECH_GEMM_PRECISION=lib: 176 ms; the full-width contours then sit at 1.19 x the 1e-4 bound against the reference
+       fixture, 0.89 x with 0: default 0). */
     int32_t precision;
     int32_t b_kshift_batch;
     /* optional hint for weight-gradient shapes (a_i == b_j == 1 with splitk_ws): the number of CUs the launch can expect to
