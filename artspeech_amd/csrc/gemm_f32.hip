@@ -34,6 +34,10 @@ struct GemmK {
     // XCD has its own L2): the chunk's operand panels are then fetched from memory once and shared by its tiles, instead of
     // (nearly) once per XCD -- the three GRU-side weight gradients of the BiGRU step: 83 -> 32 MB fetched per launch (PMC)
     int xcd_chunks;
+    // big launches of 128 x 128 tiles with a reduction-contiguous A (activations streamed from HBM, N > 128): the n-tiles of one
+    // 128-row panel of A run on ONE XCD next to each other (panel = XCD + 8 * round), so the panel is fetched once, not once
+    // per n-tile.  Only the order of the work list changes: every tile's sum is what it was, bit for bit.
+    int xcd_panels;
     float* slab;
     // optional arrival counters, one per (batch, output tile), zero between launches: the workgroup that delivers the last
     // partial of a tile sums the slabs itself (fixed k order) and runs the ordinary epilogue -- no second kernel
@@ -208,6 +212,23 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) void gemm_f32_
             const int q = wrem >> 3, rnd = q / per_split;
             x.ks = (wrem & 7) + 8 * rnd;
             xy = q - rnd * per_split;
+        }
+        if (g.xcd_panels) {
+            const long panels = (long)g.batch * tiles_m, p8 = panels & ~7L, cut = p8 * tiles_n;
+            long panel;
+            int tn;
+            if (w < cut) {
+                const long q = w >> 3, rnd = q / tiles_n;
+                tn = (int)(q - rnd * tiles_n);
+                panel = (w & 7) + 8 * rnd;
+            } else {      // the last (panels % 8) panels, plainly
+                const long r = w - cut;
+                panel = p8 + r / tiles_n;
+                tn = (int)(r % tiles_n);
+            }
+            x.bz = (int)(panel / tiles_m);
+            x.ks = 0;
+            xy = tn * tiles_m + (int)(panel - (long)x.bz * tiles_m);
         }
         x.xy = xy;
         x.tn_idx = xy / tiles_m;
@@ -824,7 +845,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
     k.a_vec = aligned16(g->A) && a_ld % 4 == 0 && g->a_batch % 4 == 0;
     k.b_vec = aligned16(g->B) && b_ld % 4 == 0 && g->b_batch % 4 == 0;
     hipStream_t st = (hipStream_t)stream;
-    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr; k.counters = nullptr; k.xcd_chunks = 0;
+    k.splitk = 1; k.kchunk = g->K; k.batch = g->batch; k.slab = nullptr; k.counters = nullptr; k.xcd_chunks = 0; k.xcd_panels = 0;
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
     k.a_off = (const long*)g->a_off; k.b_off = (const long*)g->b_off; k.c_off = (const long*)g->c_off;
     k.bias_off = (const long*)g->bias_off;
@@ -918,6 +939,8 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
                 return 0;
             }
         }
+        static const bool no_panels = AS_DIAG_SET("AS_NO_XCD_PANELS");
+        k.xcd_panels = a_kc && g->N > 128 && g->k_tri == 0 && big >= 2048 && slots % 8 == 0 && !no_panels;
         return launch<128, 128>(k, g->batch, a_kc, b_kc, st);
     }
     // few output tiles and a long reduction (weight gradients): split K over workgroups
