@@ -490,7 +490,12 @@ def main():
                 import bench_transformer
                 t_ = bench_transformer.run(32, 200, 3, dev, log)
                 c4 = dict(t_["fwd_bwd"])
+                from artspeech_amd.phoneme_to_articulation.transformer import ops as t_ops
+                names = {v: k for k, v in t_ops.PRECISIONS.items()}
                 c4.update({"workload": "ArtSpeechTransformer d=256 L=6 heads=4 A=11, B=32 T=200, fwd + masked loss + bwd, fp32",
+                           "arith": (f"forward GEMMs: {names[t_ops.GEMM_PRECISION]}; backward GEMMs (input and weight gradients): "
+                                     f"{names[t_ops.GRAD_PRECISION]} (lib = the library's matrix arithmetic, see `arith`); attention, "
+                                     "LayerNorm, softmax: fp32"),
                            "params": t_["params"], "fwd_only": t_["fwd"]})
                 extras["transformer_c4"] = c4
                 p_ = bench_pipeline.run(32, 200, 3, dev, log)
