@@ -151,7 +151,10 @@ class TrainStep:
         dist = torch.distributed
         end = self.late_off if self.pipeline else self.grads.numel()   # pipelined: [late_off, total) follows one step late
         if not self.ar_overlap:
+            cur = torch.cuda.current_stream()
+            ev = self._ar_mark("exposed", cur)     # one piece, all of it between the backward and Adam
             dist.all_reduce(self.grads[:end], op=dist.ReduceOp.SUM, group=self.pg)
+            self._ar_mark_end(ev, cur)
             return
         _lib.check(_lib.lib().as_artspeech_wait_head_grads(_lib.stream_ptr(), self.comm_stream.cuda_stream), "as_artspeech_wait_head_grads")
         cur = torch.cuda.current_stream()
