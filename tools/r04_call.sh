@@ -3,11 +3,14 @@ source $GRAFT_REPO_ROOT/tools/gpu_steps.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-export ARTSPEECH_GEMM_PRECISION=lib
-step 400 $O/fw_six.log python -m pytest tests/test_gpu_transformer.py -x -q -s -k "full_width_model_matches_reference_fixture"
-grep -h "full-width transformer contours\|passed\|failed\|assert" $O/fw_six.log | head
-export ARTSPEECH_DIAG_LIB=$R/artspeech_amd/libartspeech_hip_diag_nine.so
-step 400 $O/fw_nine.log python -m pytest tests/test_gpu_transformer.py -x -q -s -k "full_width_model_matches_reference_fixture"
-grep -h "full-width transformer contours\|passed\|failed\|assert" $O/fw_nine.log | head
-step 300 $O/bt_nine.log python tools/bench_transformer.py 32 200 4
-grep "fwd+bwd\|forward" $O/bt_nine.log
+F="--no-extras --no-cpu-baseline --no-profile --no-exact"
+for r in 0 64 32 64 0; do
+export ARTSPEECH_SIDE_RESERVE_CUS=$r
+step 200 $O/bm_$r.log python bench.py $F
+echo "reserve $r: $(grep 'ms/step' $O/bm_$r.log)"
+done
+export ARTSPEECH_SIDE_RESERVE_CUS=64
+step 120 $O/rs64.log python3 tools/recurrence_stamps.py 50
+grep -v amdgpu $O/rs64.log | tail -4
+bash tools/timeline.sh mask64 ARTSPEECH_SIDE_RESERVE_CUS=64
+cat $O/mask64_timeline.txt
