@@ -751,6 +751,31 @@ constexpr int lpu_of(int) { return 4; }
 
 }  // namespace
 
+// Exclusive CUs for the recurrences.  Their 64 long-lived workgroups share the chip with throughput-bound side work (weight
+// gradients on other streams); side workgroups that land on a recurrence's CU take issue slots and LDS bandwidth from its
+// dependent chain (layer-0 backward beside two 64 x 64-tile GEMMs: 1387 -> 1296 cycles per step without them, 124 -> 117 us).
+// A CU mask on the side streams keeps them away and doubles the step (masked queues launch slowly); instead every
+// recurrence workgroup asks for 144 KB of dynamic LDS it does not touch, so that nothing that needs LDS fits beside it and
+// the dispatcher places the side work on the other CUs.  Only while the grid leaves at least half of the CUs free;
+// ARTSPEECH_GRU_SHARED_CUS=1 turns it off.
+constexpr size_t GRU_LDS_PAD = 144 * 1024, GRU_LDS_ATTR = 152 * 1024;
+static size_t gru_lds_pad(int workgroups) {
+    static const bool off = getenv("ARTSPEECH_GRU_SHARED_CUS") != nullptr;
+    if (off) return 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    return workgroups * 2 <= cus ? GRU_LDS_PAD : 0;
+}
+// dynamic LDS beyond 64 KB needs the attribute, once per kernel; false: the kernel keeps the 64 KB limit (no padding then)
+template <typename K>
+static bool gru_lds_attr(K kernel) {
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_ATTR);
+    return e == hipSuccess;
+}
+
 static unsigned long long* g_gru_dbg = nullptr;
 static unsigned g_gru_dbg_launch = 0;   // stamps of consecutive backward launches alternate between two halves of the buffer
 constexpr int AS_GRU_TOK_LDS_MAX = 128 * 1024;   // token-sum table of the layer-0 backward recurrence (one workgroup per CU)
@@ -765,13 +790,16 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
     AS_REQUIRE((long)B * T * nd * 4 * H * 4 < (1L << 32), AS_ERR_UNSUPPORTED, "as_gru_fwd: B*T=%ld frames exceed the 32-bit offsets", (long)B * T);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B, nd);
-    const size_t shm = tokens ? (size_t)T * sizeof(int) : 0;
+    const size_t pad = gru_lds_pad(B * nd);
+    const size_t need = tokens ? (size_t)T * sizeof(int) : 0;
 #ifdef AS_DIAG
     static const int ahead = AS_DIAG_INT("AS_GRU_AHEAD", 2);   // look-ahead of the operand loads (steps)
 #endif
 #ifdef AS_DIAG   // the one-step look-ahead instantiation exists in the diagnostic build only
 #define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
     do {                                                                                                                  \
+        const size_t shm = pad > need && gru_lds_attr(gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 1>) &&                       \
+                           gru_lds_attr(gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>) ? pad : need;                          \
         if (ahead == 1)                                                                                                   \
             hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 1>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
                                (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V);                                   \
@@ -780,9 +808,12 @@ static int gru_fwd_launch(const float* gi, const int64_t* tokens, int64_t tok_st
                                (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V);                                   \
     } while (0)
 #else
-#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                     \
-    hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
-                       (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V)
+#define AS_GRU_LAUNCH(HH, TR, TK)                                                                                         \
+    do {                                                                                                                  \
+        const size_t shm = pad > need && gru_lds_attr(gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>) ? pad : need;            \
+        hipLaunchKernelGGL((gru_fwd_kernel<HH, lpu_of(HH), TR, TK, 2>), grid, dim3(lpu_of(HH) * HH), shm, st, gi, tokens, \
+                           (long)tok_stride, w_hh, b_hh, lengths, T, y, gates, nd, V);                                    \
+    } while (0)
 #endif
 #define AS_GRU_FWD(HH)                                      \
     if (gates && tokens) AS_GRU_LAUNCH(HH, true, true);     \
@@ -844,18 +875,17 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
 #ifdef AS_DIAG
     static const bool unit_layout = AS_DIAG_SET("AS_GRU_BWD_UNIT");  // ablation: the 4-lanes-per-unit layout
 #endif
-    const size_t shm = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
+    const size_t pad = gru_lds_pad(B * 2);
+    const size_t need = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
 #ifdef AS_DIAG
     static const int ahead = AS_DIAG_INT("AS_GRU_AHEAD", 2);   // look-ahead of the operand loads (steps)
 #endif
 #define AS_GRU_BWD_ROW(HH, TK, AH)                                                                                            \
     do {                                                                                                                      \
-        if (TK) {                                                                                                             \
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_row_kernel<HH, TK, AH>), \
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, AS_GRU_TOK_LDS_MAX); \
-            AS_REQUIRE(attr == hipSuccess, (int)attr, "as_gru_bidir_bwd: cannot reserve LDS: %s", hipGetErrorString(attr));   \
-        }                                                                                                                     \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), TK ? shm : 0, st, dy, y, gates, w_hh,        \
+        const bool big = gru_lds_attr(gru_bwd_row_kernel<HH, TK, AH>);                                                        \
+        AS_REQUIRE(big || need <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: cannot reserve %zu bytes of LDS", need);   \
+        const size_t shm = big && pad > need ? pad : need;                                                                    \
+        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), shm, st, dy, y, gates, w_hh,                 \
                            lengths, T, dgi, dgh, dbg_now, tokens, (long)tok_stride, V, part);                                 \
     } while (0)
 #ifdef AS_DIAG   // other look-aheads and the 4-lanes-per-unit layout exist in the diagnostic build only

@@ -3,14 +3,11 @@ source $GRAFT_REPO_ROOT/tools/gpu_steps.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
+step 600 $O/t_gru.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_train.py tests/test_gpu_principal_components.py -x -q -k "gru or token or artspeech or engine or full_size or raw or hidden"
+tail -3 $O/t_gru.log
 F="--no-extras --no-cpu-baseline --no-profile --no-exact"
-for r in 0 64 32 64 0; do
-export ARTSPEECH_SIDE_RESERVE_CUS=$r
-step 200 $O/bm_$r.log python bench.py $F
-echo "reserve $r: $(grep 'ms/step' $O/bm_$r.log)"
+for r in 1 0 1 0 1 0; do
+if [ $r = 1 ]; then export ARTSPEECH_GRU_SHARED_CUS=1; else unset ARTSPEECH_GRU_SHARED_CUS; fi
+step 200 $O/bx_$r.log python bench.py $F
+echo "shared $r: $(grep 'ms/step' $O/bx_$r.log)" | tee -a $O/gru_exclusive_ab.log
 done
-export ARTSPEECH_SIDE_RESERVE_CUS=64
-step 120 $O/rs64.log python3 tools/recurrence_stamps.py 50
-grep -v amdgpu $O/rs64.log | tail -4
-bash tools/timeline.sh mask64 ARTSPEECH_SIDE_RESERVE_CUS=64
-cat $O/mask64_timeline.txt
