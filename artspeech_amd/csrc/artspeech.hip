@@ -553,6 +553,18 @@ int record_heads_done(hipStream_t owner, hipStream_t s) {
     return 0;
 }
 
+// fork whose event the producing kernel may already carry (as_stop_event_set before its launch): `left` = what
+// as_stop_event_take() returned after the launch -- non-null: nobody consumed it, record it the ordinary way
+int fork_after(hipStream_t from, hipStream_t to, hipEvent_t ev, hipEvent_t left) {
+    hipError_t e = left ? hipEventRecord(ev, from) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+    if (e != hipSuccess) {
+        as_set_error("stream fork failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
 int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
     hipError_t e = hipEventRecord(ev, from);
     if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
@@ -806,9 +818,12 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // beside the head / input-projection ones instead of queueing behind them: -9 us per step
     hipStream_t s3 = (sd && sd->side2) ? sd->side2 : s2;
     float* sl3 = (sd && sd->side2) ? ws + w.head + hw.slab3 : sl2;
+    static const bool plain_forks = AS_DIAG_SET("AS_PLAIN_FORKS");   // ablation: every fork an event record on `st`
+    // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence.  The fork's event rides on the GEMM's own
+    // dispatch (as_stop_event_set): no marker packet on `st` between it and the recurrence
+    if (sd && !plain_forks) as_stop_event_set(sd->fork[0]);
     AS_STEP("trunkb.dx", st, gemm_nn(dzlin, H, P + L.lin_w, 2 * H, ws + w.dy1, 2 * H, R, 2 * H, H, st));
-    // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence
-    if (sd) AS_TRY(fork_to(st, s2, sd->fork[0]));
+    if (sd) AS_TRY(fork_after(st, s2, sd->fork[0], plain_forks ? sd->fork[0] : as_stop_event_take()));
     AS_STEP("gru.bwd_l1", st, as_gru_bidir_bwd(ws + w.dy1, ws + w.y1, ws + w.g1, P + L.w_hh[1], lengths, B, T, H, ws + w.dgi1, ws + w.dgh1, st));
     const int side_cus = sd ? 192 : 0;  // the recurrence's 2 * B workgroups hold 64 CUs while the side stream works
     const TrunkJob trunk{dzlin, ws + w.y1, G + L.lin_w, G + L.lin_b, H};
@@ -820,6 +835,8 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
                        defer ? 5 : -1));
     // [lin_w, total) of the flat gradient buffer is final from here on ([lin_w, ln2_g) with defer_dw2)
     if (!two_parts || defer) AS_TRY(record_heads_done(st, s2));
+    hipEvent_t fork1_left = nullptr;
+    bool fork1_armed = false;
     {
         // input gradient of GRU layer 1: [R][6H] . [6H][2H].  (diagnostic build, AS_DX1_LIN: the LDS-DMA kernel of the head
         // layers on 32-row x 256-column tiles instead of the general kernel's 64 x 64 tiles + in-kernel split-K)
@@ -836,13 +853,17 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
             AS_REQUIRE(took >= 0, took, "grub.dx1: launch failed");
         }
         // (split arithmetic measured slower here, 56 vs 52 us: 200 workgroups x 1.2 MB of weight planes each from L2)
-        if (!took)
+        if (!took) {
+            if (sd && !plain_forks && !(pdrop > 0.f)) as_stop_event_set(sd->fork[1]);   // fork 1 rides on this GEMM (see fork 0)
             AS_STEP("grub.dx1", st, gemm_nn(ws + w.dgi1, 6 * H, P + L.w_ih[1], 2 * H, ws + w.dy0, 2 * H, R, 2 * H, 6 * H, st, 1, 0, 0, 0, slab));
+            fork1_left = as_stop_event_take();
+            fork1_armed = sd && !plain_forks && !(pdrop > 0.f);
+        }
     }
     if (pdrop > 0.f)  // back through the inter-layer dropout: same mask, regenerated from the seed
         AS_STEP("gru.dropout", st, as_dropout(ws + w.dy0, ws + w.dy0, (long)R * 2 * H, pdrop, opts->dropout_seed, st));
     // ---- fork 1: layer-1 weight gradients run beside the layer-0 recurrence
-    if (sd) AS_TRY(fork_to(st, s2, sd->fork[1]));
+    if (sd) AS_TRY(fork_after(st, s2, sd->fork[1], fork1_armed ? fork1_left : sd->fork[1]));
     if (s3 != s2) {   // ONE record on `st` for both side streams (every event record is a barrier packet on the critical stream)
         const hipError_t e = hipStreamWaitEvent(s3, sd->fork[1], 0);
         AS_REQUIRE(e == hipSuccess, (int)e, "as_artspeech_bwd: stream wait failed: %s", hipGetErrorString(e));
@@ -851,6 +872,8 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // leaves B tables [V][6H] where dgi0 would have gone (V <= T: they fit), so there is no dgi0 and no segmented-sum
     // pass; else dgi0 + as_token_segsum below
     const int tok_sums = V <= T && as_gru_bwd_tokens_fits(V, H, T);
+    // fork 2 (the tail's second job, below) rides on the recurrence's dispatch
+    if (sd && !plain_forks) as_stop_event_set(s3 != s2 ? sd->fork2[2] : sd->fork[2]);
     if (tok_sums) {
         AS_PROF("gru.bwd_l0", st);
         const int rc = as_gru_bidir_bwd_tokens(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgh0, tokens,
@@ -859,6 +882,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     } else {
         AS_STEP("gru.bwd_l0", st, as_gru_bidir_bwd(ws + w.dy0, ws + w.y0, ws + w.g0, P + L.w_hh[0], lengths, B, T, H, ws + w.dgi0, ws + w.dgh0, st));
     }
+    const hipEvent_t fork2_left = (sd && !plain_forks) ? as_stop_event_take() : (sd ? (s3 != s2 ? sd->fork2[2] : sd->fork[2]) : nullptr);
     if (two_parts && !defer) {
         AS_TRY(head_bwd_dw(*d, L, P, R, G, hws, sl2, s2, dpre3, side_cus, sd ? SLAB2_FLOATS : SLAB_FLOATS, nullptr, 2));
         AS_TRY(record_heads_done(st, s2));  // [lin_w, total) of the flat gradient buffer is final from here on
@@ -874,7 +898,7 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     //   otherwise: segmented sum + embedding grads (~40 us) here, the GEMM aside.
     hipStream_t s_hh = tok_sums ? st : s3, s_emb = tok_sums ? s3 : st;
     float* sl_hh = tok_sums ? slab : sl3;
-    if (sd) AS_TRY(fork_to(st, s3, s3 != s2 ? sd->fork2[2] : sd->fork[2]));
+    if (sd) AS_TRY(fork_after(st, s3, s3 != s2 ? sd->fork2[2] : sd->fork[2], fork2_left));
     AS_STEP("grub.dw_hh", s_hh, gemm_tn(ws + w.dgh0, 6 * H, ws + w.y0, 2 * H, G + L.w_hh[0], H, 3 * H, H, R, s_hh, sl_hh, G + L.b_hh[0], 3 * H, 2,
                    3 * H, H, 3L * H * H, -1, T, 2));
     // embedding + layer-0 input projection through the token table

@@ -35,3 +35,12 @@ int as_matrix_arith() {
 }
 extern "C" void as_set_matrix_arith(int32_t mode) { g_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int32_t as_get_matrix_arith(void) { return as_matrix_arith(); }
+
+// ---- see gemm_internal.h: the event the next knowing kernel launch of this thread binds to its completion
+static thread_local void* g_stop_event = nullptr;
+void as_stop_event_set_raw(void* ev) { g_stop_event = ev; }
+void* as_stop_event_take_raw() {
+    void* e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}

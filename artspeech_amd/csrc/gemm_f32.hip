@@ -12,6 +12,8 @@
 #include <mutex>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "gemm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -768,11 +770,14 @@ int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 block(256);
     // FAST needs whole float4s: aligned operands and contiguous extents that are multiples of 4
     const bool fast = k.a_vec && k.b_vec && (a_kc ? k.K % 4 == 0 : k.M % 4 == 0) && (b_kc ? k.K % 4 == 0 : k.N % 4 == 0);
+    // the call's last kernel (no reduce kernel behind it) may carry a fork event (gemm_internal.h, as_stop_event_set)
+    hipEvent_t stop_ev = (k.splitk == 1 || k.counters != nullptr) ? as_stop_event_take() : nullptr;
 #define AS_GEMM_LAUNCH(AK, BK_, F)                                                                   \
     do {                                                                                             \
         static const int slots = resident_blocks(gemm_f32_kernel<BM, BN, AK, BK_, F>);               \
         const dim3 grid((unsigned)(work < slots ? work : slots));                                    \
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);            \
+        if (stop_ev) hipExtLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, nullptr, stop_ev, 0, k); \
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, F>), grid, block, 0, st, k);       \
     } while (0)
     if (k.res || k.mask_bits || k.relu_bits || k.k_seg > 0 || k.k_tri != 0) {   // the extended instantiations (operands checked by as_gemm_f32)
 #define AS_GEMM_LAUNCH_EXT(AK, BK_)                                                                    \

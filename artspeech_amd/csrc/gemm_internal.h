@@ -47,6 +47,15 @@ int as_gemm_s6_nt(const float* A, long lda, long a_batch, const float* B, long l
 int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st);
 template <int N> struct IC2 { static constexpr int value = N; };
 
+// A cross-stream fork without a barrier packet on the producing stream: the event is bound to the completion of the NEXT kernel
+// this thread launches through a launch site that knows the mechanism (hipExtLaunchKernelGGL's stopEvent: the dispatch packet's
+// own completion signal), instead of hipEventRecord's marker packet behind it (~7 us on the stream that records it, measured on
+// the step timeline).  as_stop_event_take(): the event if no launch has consumed it (the caller then records it the ordinary way).
+void as_stop_event_set_raw(void* ev);
+void* as_stop_event_take_raw();
+inline void as_stop_event_set(hipEvent_t ev) { as_stop_event_set_raw((void*)ev); }
+inline hipEvent_t as_stop_event_take() { return (hipEvent_t)as_stop_event_take_raw(); }
+
 // lin_f32.hip: one Linear of the ArticulatorPredictor heads with the adjoining LayerNorm fused in (batched over heads):
 //   C[bz] = epilogue(A[bz] [M][K] . B[bz]),  B[bz] = [N][K] (b_kc: forward) or [K][N] (backward); N <= 256, K % 32 == 0.
 //   epi 0: act(. + bias) (act as as_gemm: 0 none, 1 ReLU, 2 sigmoid)

@@ -29,6 +29,8 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "as_common.h"
 #include "gemm_internal.h"
 
@@ -875,6 +877,7 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
 #ifdef AS_DIAG
     static const bool unit_layout = AS_DIAG_SET("AS_GRU_BWD_UNIT");  // ablation: the 4-lanes-per-unit layout
 #endif
+    hipEvent_t stop_ev = (H == 32 || H == 64 || H == 128) ? as_stop_event_take() : nullptr;
     const size_t pad = gru_lds_pad(B * 2);
     const size_t need = tokens ? ((size_t)V * 3 * H + 4 * H + T) * sizeof(float) : 0;   // + one dummy word per lane + T offsets
 #ifdef AS_DIAG
@@ -885,16 +888,22 @@ static int gru_bwd_launch(const float* dy, const float* y, const float* gates, c
         const bool big = gru_lds_attr(gru_bwd_row_kernel<HH, TK, AH>);                                                        \
         AS_REQUIRE(big || need <= 64 * 1024, AS_ERR_UNSUPPORTED, "as_gru_bidir_bwd: cannot reserve %zu bytes of LDS", need);   \
         const size_t shm = big && pad > need ? pad : need;                                                                    \
-        hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), shm, st, dy, y, gates, w_hh,                 \
-                           lengths, T, dgi, dgh, dbg_now, tokens, (long)tok_stride, V, part);                                 \
+        if (stop_ev)   /* a fork event rides on this dispatch (gemm_internal.h, as_stop_event_set) */                         \
+            hipExtLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), (unsigned)shm, st, nullptr, stop_ev, 0, dy, y, \
+                                  gates, w_hh, lengths, T, dgi, dgh, dbg_now, tokens, (long)tok_stride, V, part);             \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((gru_bwd_row_kernel<HH, TK, AH>), grid, dim3(4 * HH), shm, st, dy, y, gates, w_hh,             \
+                               lengths, T, dgi, dgh, dbg_now, tokens, (long)tok_stride, V, part);                             \
     } while (0)
 #ifdef AS_DIAG   // other look-aheads and the 4-lanes-per-unit layout exist in the diagnostic build only
 #define AS_GRU_BWD(HH)                                                                                                        \
     if (tokens) {                                                                                                             \
         if (ahead == 3) AS_GRU_BWD_ROW(HH, true, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, true, 2); else AS_GRU_BWD_ROW(HH, true, 1); \
-    } else if (unit_layout)                                                                                                   \
+    } else if (unit_layout) {                                                                                                 \
         hipLaunchKernelGGL((gru_bwd_kernel<HH, lpu_of(HH)>), grid, dim3(lpu_of(HH) * HH), 0, st, dy, y, gates, w_hh, lengths, \
                            T, dgi, dgh);                                                                                      \
+        if (stop_ev) (void)hipEventRecord(stop_ev, st);                                                                       \
+    }                                                                                                                         \
     else if (ahead == 3) AS_GRU_BWD_ROW(HH, false, 3); else if (ahead == 2) AS_GRU_BWD_ROW(HH, false, 2); else AS_GRU_BWD_ROW(HH, false, 1)
 #else
 #define AS_GRU_BWD(HH) \
