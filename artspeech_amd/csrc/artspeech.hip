@@ -896,6 +896,11 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // stays on the caller's stream, back to back with the recurrence, and the shorter one forks off.
     //   token sums in the recurrence: hidden-to-hidden GEMM (~30 us) here, table reduction + embedding grads (~13 us) aside;
     //   otherwise: segmented sum + embedding grads (~40 us) here, the GEMM aside.
+    // The first side stream has its last work of this call queued: the second one waits for it HERE, before its own tail work --
+    // a wait that resolves while that stream idles through the recurrence -- so that the final join is one hop (second side
+    // stream -> `st`) instead of two (14.6 -> 11 us between the last kernel and Adam; chained form: AS_CHAIN_JOIN).
+    static const bool chain_join = AS_DIAG_SET("AS_CHAIN_JOIN");
+    if (sd && s3 != s2 && !chain_join) AS_TRY(fork_to(s2, s3, sd->join));
     hipStream_t s_hh = tok_sums ? st : s3, s_emb = tok_sums ? s3 : st;
     float* sl_hh = tok_sums ? slab : sl3;
     if (sd) AS_TRY(fork_after(st, s3, s3 != s2 ? sd->fork2[2] : sd->fork[2], fork2_left));
@@ -917,7 +922,11 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     }
     // join: `st` continues only after the side streams' work.  One wait on `st` (each costs the tail a few microseconds):
     // the second side stream first waits for the first one, then `st` waits for it alone.
-    if (sd && s3 != s2) {
+    if (sd && s3 != s2 && !chain_join) {
+        // the second side stream already waited for the first one (above, before its tail work): one record behind its last
+        // kernel, one wait on `st`
+        AS_TRY(fork_to(s3, st, sd->join2));
+    } else if (sd && s3 != s2) {
         AS_TRY(fork_to(s2, s3, sd->join));
         AS_TRY(fork_to(s3, st, sd->join2));
     } else if (sd) {
