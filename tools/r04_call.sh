@@ -3,13 +3,10 @@ source $GRAFT_REPO_ROOT/tools/gpu_steps.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-export ARTSPEECH_DIAG_LIB=$R/artspeech_amd/libartspeech_hip_diag.so
+step 600 $O/t_tr.log python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -x -q -k "engine or artspeech or train or full_size or run_epoch"
+tail -3 $O/t_tr.log
+bash tools/timeline.sh loss
+sed -n 16,24p $O/loss_timeline.txt
 F="--no-extras --no-cpu-baseline --no-profile --no-exact"
-for r in 0 1 0 1 0 1 0 1; do
-if [ $r = 1 ]; then export AS_CHAIN_JOIN=1; else unset AS_CHAIN_JOIN; fi
-step 200 $O/bj_$r.log python bench.py $F
-echo "chain join $r: $(grep 'ms/step' $O/bj_$r.log)" | tee -a $O/join_ab.log
-done
-unset AS_CHAIN_JOIN ARTSPEECH_DIAG_LIB
-bash tools/timeline.sh joins
-tail -6 $O/joins_timeline.txt
+step 200 $O/bl.log python bench.py $F
+grep "ms/step" $O/bl.log
