@@ -276,11 +276,11 @@ int head_fwd_impl(const as_dims& d, const as_layout& L, const float* P, const fl
         int n_part = 0;
         if (crit) {
             lo.tgt = crit->tgt; lo.tgt_T = crit->tgt_T; lo.lengths = crit->lengths; lo.T = crit->T; lo.scale = crit->scale;
-            lo.dout = crit->dout; lo.partial = ws + w.lpart; lo.partial_capacity = w.lpart_n;
+            lo.dout = crit->dout; lo.partial = ws + w.lpart; lo.partial_capacity = w.lpart_n; lo.loss = crit->loss;
         }
         took = as_lin_out_try(&lo, &n_part, st);
         AS_REQUIRE(took >= 0, took, "head gemm3: launch failed");
-        if (took && crit) AS_TRY(as_loss_final(ws + w.lpart, n_part, crit->scale, crit->loss, st));
+        if (took && crit && n_part > 0) AS_TRY(as_loss_final(ws + w.lpart, n_part, crit->scale, crit->loss, st));   // (0: summed in the kernel)
         crit_done = took && crit;
         if (!took) {
             took = as_lin_try(&l3, st);

@@ -764,6 +764,15 @@ int* counters_for(hipStream_t st) {
     return p;
 }
 
+}  // namespace
+// see gemm_internal.h: the last word of the stream's counter block (the split-K kernel uses the first tiles-per-launch words; all
+// users run on the stream in order and leave their counters zero)
+int* as_arrival_counter(hipStream_t st) {
+    int* p = counters_for(st);
+    return p ? p + (COUNTERS - 1) : nullptr;
+}
+namespace {
+
 template <int BM, int BN>
 int launch(const GemmK& k, int batch, bool a_kc, bool b_kc, hipStream_t st) {
     const long work = (long)as_cdiv(k.M, BM) * as_cdiv(k.N, BN) * k.splitk * batch;
@@ -971,7 +980,7 @@ extern "C" int as_gemm_f32(const as_gemm* g, void* stream) {
             // few slabs: the last workgroup to arrive at a tile sums them in the kernel (input gradient of GRU layer 1, 3 slabs:
             // 52 us against 36 + 45 for a reduce kernel that has to squeeze in beside the side stream's persistent GEMM).
             // Many slabs (a handful of tiles) would leave the sums to a handful of workgroups: the wide reduce kernel then.
-            if (k.splitk <= 16 && tiles <= COUNTERS) k.counters = counters_for(st);
+            if (k.splitk <= 16 && tiles < COUNTERS) k.counters = counters_for(st);
         }
     }
     AS_TRY((launch<64, 64>(k, g->batch, a_kc, b_kc, st)));

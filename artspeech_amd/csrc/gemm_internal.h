@@ -101,8 +101,16 @@ struct as_lin_out {
     const float* tgt; long tgt_T; const int* lengths; int T; float scale;
     float* dout; float* partial; long partial_capacity;
     const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // optional: B as bfloat16 planes, bp_rows >= 128 (see as_lin.Bp)
+    // optional with tgt: the device scalar that receives scale * sum of the partials.  The workgroup that delivers the LAST partial
+    // adds them all itself, in the order of as_loss_final (same value): no second launch on the critical stream.  Needs an arrival
+    // counter (as_arrival_counter); without one the partials are left for as_loss_final as before (*n_partials > 0).
+    float* loss;
 };
+// 1 = launched (fused criterion: *n_partials workgroup sums were written to `partial` and await as_loss_final; 0 of them when the
+// kernel has summed them into a->loss itself), 0 = not a case, < 0 = error
 int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st);
+// gemm_f32.hip: one of the stream's arrival counters (a device word that every launch leaves zero), or nullptr
+int* as_arrival_counter(hipStream_t st);
 // metrics.hip: *loss = scale * sum of the first n partials (fixed order)
 int as_loss_final(const float* partial, int n, float scale, float* loss, hipStream_t st);
 

@@ -920,7 +920,37 @@ struct LinOutK {
     const float* tgt; long tgt_T; const int* lengths; int T; float scale;
     float* dout; float* partial;
     const uint16_t* Bp; long bp_plane, bp_batch; int bp_rows;   // lin_out_s6_kernel: W3' as bfloat16 planes (as_lin_out.Bp)
+    float* loss; int* counter;                                  // the last workgroup sums the partials (as_lin_out.loss)
 };
+
+// The criterion's workgroup sum goes out; with an arrival counter the workgroup that delivers the last one adds them all, thread
+// i taking partials i, i + 256, ... and the 256 sums meeting as in loss_final_kernel (metrics.hip): the same value, bit for bit.
+// Partials are written through to memory and read back at agent scope (another XCD's L2 does not see a plain store: gemm_f32.hip).
+__device__ __forceinline__ void criterion_tail(const LinOutK& g, int tile, float sum, int tid, float* red, int nwaves) {
+    if (g.counter == nullptr) {
+        if (tid == 0) g.partial[tile] = sum;
+        return;
+    }
+    __shared__ int s_last;
+    if (tid == 0) {
+        __hip_atomic_store(&g.partial[tile], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int last = atomicAdd(g.counter, 1) == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float s = 0.f;
+    if (tid < 256)
+        for (int i = tid; i < (int)gridDim.x; i += 256) s += __hip_atomic_load(&g.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = as_wave_sum(s);
+    __syncthreads();                 // `red` held the workgroup's own wave sums until here
+    if ((tid & 63) == 0 && tid < 256) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) g.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * g.scale;
+    (void)nwaves;
+}
 
 __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
     constexpr int TILE = BK * (64 + ON);
@@ -1088,7 +1118,9 @@ __global__ __launch_bounds__(NT, 4) void lin_out_kernel(LinOutK g) {
     __shared__ float red[8];
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    if (tid == 0) g.partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    float wg_sum = 0.f;
+    if (tid == 0) wg_sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    criterion_tail(g, blockIdx.x, wg_sum, tid, red, 8);
 }
 
 // The output layer on the bf16 matrix instruction (see lin_s6_kernel): 4 waves, wave w = columns 32 w .. 32 w + 31 of all 64
@@ -1222,7 +1254,9 @@ __global__ __launch_bounds__(256, 4) void lin_out_s6_kernel(LinOutK g) {
     __shared__ float red[4];
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    if (tid == 0) g.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);   // (tile order, like lin_out_kernel: same final sum order)
+    float wg_sum = 0.f;
+    if (tid == 0) wg_sum = (red[0] + red[1]) + (red[2] + red[3]);   // (tile order, like lin_out_kernel: same final sum order)
+    criterion_tail(g, tile, wg_sum, tid, red, 4);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1422,18 +1456,24 @@ int as_lin_out_try(const as_lin_out* a, int* n_partials, hipStream_t st) {
     const long total = (long)k.n_big + (long)k.small_per_batch * k.batch;
     if (k.small_per_batch == 0) k.small_per_batch = 1;
     if (k.tgt && total > a->partial_capacity) return 0;
+    static const bool no_tail = AS_DIAG_SET("AS_NO_LOSS_TAIL");   // ablation: the separate final-sum kernel
+    if (k.tgt && a->loss && !no_tail) {
+        k.counter = as_arrival_counter(st);
+        k.loss = k.counter ? a->loss : nullptr;
+    }
+    const int left = k.counter ? 0 : (int)total;   // partials that still await as_loss_final
     static const bool no_s6 = AS_DIAG_SET("AS_NO_LIN_OUT_S6");   // diagnostic: the output layer on the fp32 instruction
     if (!no_s6 && a->Bp && as_matrix_arith() == AS_ARITH_BF16X6 && a->K % S6_BK == 0 && a->bp_rows >= ON && (reinterpret_cast<uintptr_t>(a->Bp) & 15) == 0 &&
         a->bp_plane % 8 == 0 && a->bp_batch % 8 == 0 && a->lda < (1L << 23)) {
         k.Bp = a->Bp; k.bp_plane = a->bp_plane; k.bp_batch = a->bp_batch; k.bp_rows = a->bp_rows;
         hipLaunchKernelGGL(lin_out_s6_kernel, dim3((unsigned)total), dim3(256), 0, st, k);
         AS_LAUNCH_CHECK("as_lin_out_s6");
-        if (n_partials) *n_partials = (int)total;
+        if (n_partials) *n_partials = left;
         return 1;
     }
     hipLaunchKernelGGL(lin_out_kernel, dim3((unsigned)total), dim3(NT), 0, st, k);
     AS_LAUNCH_CHECK("as_lin_out");
-    if (n_partials) *n_partials = (int)total;
+    if (n_partials) *n_partials = left;
     return 1;
 }
 
