@@ -818,7 +818,10 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // beside the head / input-projection ones instead of queueing behind them: -9 us per step
     hipStream_t s3 = (sd && sd->side2) ? sd->side2 : s2;
     float* sl3 = (sd && sd->side2) ? ws + w.head + hw.slab3 : sl2;
-    static const bool plain_forks = AS_DIAG_SET("AS_PLAIN_FORKS");   // ablation: every fork an event record on `st`
+    // ablation (AS_PLAIN_FORKS): every fork an event record on `st`.  Also while the per-phase timers are on (as_profile_enable):
+    // a timing event recorded right behind an event-carrying dispatch reads ~20 us late, which would inflate the phase.
+    static const bool plain_forks_env = AS_DIAG_SET("AS_PLAIN_FORKS");
+    const bool plain_forks = plain_forks_env || as_profile_active();
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence.  The fork's event rides on the GEMM's own
     // dispatch (as_stop_event_set): no marker packet on `st` between it and the recurrence
     if (sd && !plain_forks) as_stop_event_set(sd->fork[0]);

@@ -54,6 +54,7 @@ struct AsProfScope {
     ~AsProfScope();
     const char* name_; hipStream_t st_; void* a_; void* b_;
 };
+bool as_profile_active();   // as_profile_enable(1) is in force
 #define AS_PROF_CAT2(a, b) a##b
 #define AS_PROF_CAT(a, b) AS_PROF_CAT2(a, b)
 #define AS_PROF(name, st) AsProfScope AS_PROF_CAT(as_prof_scope_, __LINE__)(name, st)

@@ -38,6 +38,7 @@ AsProfScope::~AsProfScope() {
 }
 
 extern "C" void as_profile_enable(int32_t on) { g_on = on != 0; }
+bool as_profile_active() { return g_on; }
 extern "C" void as_profile_reset(void) {
     g_recs.clear();
     g_next = 0;
