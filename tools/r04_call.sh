@@ -3,12 +3,12 @@ source $GRAFT_REPO_ROOT/tools/gpu_steps.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-F="--no-extras --no-cpu-baseline --no-exact --steps 50 --warmup 10"
-step 200 $O/p_new.log python bench.py $F
+step 300 $O/smoke.log python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+tail -2 $O/smoke.log
+step 400 $O/driver_style.json python3 bench.py --gpus 1 --steps 20 --warmup 5
 python3 - <<'PY'
 import json
-l=[x for x in open("gpurun_out/p_new.log") if x.startswith('{')][-1]
+l=[x for x in open("gpurun_out/driver_style.json") if x.startswith('{')][-1]
 d=json.loads(l)
-k=d['kernels_us_per_step']
-print(d['ms_per_step'], {n:k[n]['us_per_step'] for n in ['gru.fwd_l0','gru.bwd_l1','gru.bwd_l0','grub.dx1','trunkb.dx']}, d['roofline']['us_per_launch'])
+print('driver-style', d['ms_per_step'], d['value'], d['exact_fp32']['ms_per_step'], d['transformer_c4']['ms_per_step'])
 PY
