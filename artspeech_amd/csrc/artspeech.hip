@@ -821,7 +821,9 @@ extern "C" int as_artspeech_bwd(const as_dims* d, const float* P, const int64_t*
     // ablation (AS_PLAIN_FORKS): every fork an event record on `st`.  Also while the per-phase timers are on (as_profile_enable):
     // a timing event recorded right behind an event-carrying dispatch reads ~20 us late, which would inflate the phase.
     static const bool plain_forks_env = AS_DIAG_SET("AS_PLAIN_FORKS");
-    const bool plain_forks = plain_forks_env || as_profile_active();
+    hipStreamCaptureStatus cap_ = hipStreamCaptureStatusNone;   // inside a stream capture: ordinary event records (graph edges)
+    const bool capturing = hipStreamIsCapturing(st, &cap_) != hipSuccess || cap_ != hipStreamCaptureStatusNone;
+    const bool plain_forks = plain_forks_env || as_profile_active() || capturing;
     // ---- fork 0: head + trunk weight gradients run beside the layer-1 recurrence.  The fork's event rides on the GEMM's own
     // dispatch (as_stop_event_set): no marker packet on `st` between it and the recurrence
     if (sd && !plain_forks) as_stop_event_set(sd->fork[0]);
