@@ -46,6 +46,11 @@ __device__ __forceinline__ float unit_sum(float v) {
     return v;
 }
 
+#ifdef AS_GRU_NO_GATE_SHARE
+constexpr bool GATE_SHARE = false;
+#else
+constexpr bool GATE_SHARE = true;
+#endif
 template <int H, int LPU, bool TRAIN, bool TOK, int AHEAD>
 __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restrict__ gi, const int64_t* __restrict__ tokens,
                                                           long tok_stride, const float* __restrict__ w_hh,
@@ -146,8 +151,19 @@ __global__ __launch_bounds__(LPU * H) void gru_fwd_kernel(const float* __restric
                 }
         }
         const float sr = unit_sum<LPU>(ar.x + ar.y), sz = unit_sum<LPU>(az.x + az.y), sn = unit_sum<LPU>(an.x + an.y);
-        const float r = as_sigmoid(ci.r + sr);
-        const float z = as_sigmoid(ci.z + sz);
+        float r, z;
+        if constexpr (LPU == 4 && GATE_SHARE) {
+            // the four lanes of a unit hold the same sums: lane 0 takes r's sigmoid, lanes 1..3 z's -- ONE exp + rcp sequence per
+            // lane instead of two (quarter-rate instructions: 32 of the step's ~410 issue cycles per wave) -- and two quad
+            // broadcasts hand both to every lane.  Same operations on the same values: bit-identical.
+            const float pre = __int_as_float((__float_as_int(ci.r + sr) & m0) | (__float_as_int(ci.z + sz) & ~m0));
+            const float sg = as_sigmoid(pre);
+            r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+            z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0x55, 0xF, 0xF, true));   // quad_perm [1,1,1,1]
+        } else {
+            r = as_sigmoid(ci.r + sr);
+            z = as_sigmoid(ci.z + sz);
+        }
         const float hn = sn;
         const float n = as_tanh(ci.n + r * hn);
         const float hnew = (1.f - z) * n + z * h;
