@@ -62,6 +62,7 @@ struct S6K {
     int k_seg, nseg; const long* a_seg_off; const long* b_seg_off;
     float* colsum; long colsum_batch;      // A column-contiguous only: colsum[g][m] = sum_k A[g][k][m]
     int xcd_group, batch;                  // > 0: tiles per batch member, all on one XCD (see the kernel)
+    int vec_epi;                           // float4-clean output side (N, ldc, res_ld multiples of 4, 16-byte aligned bases): row-major epilogue
 };
 
 typedef const __attribute__((address_space(1))) char* gptr;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     Regs x[2];
     load(x[0]);
     load(x[1]);
-    if (EXT && g.res) {   // the accumulators start from `res` (requested behind the first two tiles' loads)
+    if (EXT && g.res && !g.vec_epi) {   // scalar epilogue: the accumulators start from `res` (requested behind the first two tiles' loads)
         const float* R = g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -326,6 +327,62 @@ __global__ __launch_bounds__(NTH, 3) void gemm_s6_kernel(S6K g) {
     // ---- epilogue: D[i][j] block (i, j) of the wave: row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = n0 + wn * 64 + j * 32 + l31
     float* C = g.C + (g.c_off ? g.c_off[bz] : (long)bz * g.c_batch);
     const float* bias = g.bias ? g.bias + (g.bias_off ? g.bias_off[bz] : (long)bz * g.bias_batch) : nullptr;
+    if (g.vec_epi) {
+        // Row-major epilogue: the accumulators leave in two halves of 64 rows through LDS ([64][128 + 4] floats: the matrix
+        // instruction's layout gives a lane one column of 16 rows -- 64 dword stores, and as many dword loads each for `res` and
+        // the mask words), and every thread handles float4s of consecutive columns: 8 stores, 8 `res` loads, 8 mask words
+        // per thread and half.  At K = 256 the old form issued three times the vector-memory instructions of the main loop
+        // (the extended input-gradient launches ran at 77 TF/s-equivalent against 178 for the plain ones).
+        // `res` is added here, behind the reduction: (sum_k) + res + bias -- the fp32 kernel starts its accumulators from it.
+        constexpr int LD = TB + 4;
+        float* es = reinterpret_cast<float*>(sm);
+        const float* R = (EXT && g.res) ? g.res + (g.res_off ? g.res_off[bz] : (long)bz * g.res_batch) : nullptr;
+        const unsigned* mask = (EXT && g.mask_bits) ? g.mask_bits + (long)bz * g.mask_batch : nullptr;
+        unsigned* bits = g.relu_bits ? g.relu_bits + (long)bz * g.relu_bits_batch : nullptr;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            es[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LD + wn * 64 + j * 32 + l31] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = tid + NTH * u, rr = id >> 5, c4 = id & 31;
+                const int row = m0 + 64 * half + rr, col = n0 + 4 * c4;
+                const bool ok = row < g.M && col < g.N;      // (N % 4 == 0: a float4 is inside or outside as a whole)
+                f32x4 v = *reinterpret_cast<const f32x4*>(es + rr * LD + 4 * c4);
+                if (ok) {
+                    if (R) v += *reinterpret_cast<const f32x4*>(R + (long)row * g.res_ld + col);
+                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                    if (g.act == 1) { v.x = as_relu(v.x); v.y = as_relu(v.y); v.z = as_relu(v.z); v.w = as_relu(v.w); }
+                    else if (g.act == 2) { v.x = as_sigmoid(v.x); v.y = as_sigmoid(v.y); v.z = as_sigmoid(v.z); v.w = as_sigmoid(v.w); }
+                    if (mask) {
+                        const unsigned nib = mask[(long)row * g.ncb + (col >> 5)] >> (col & 31);
+                        v.x = (nib & 1u) ? v.x : 0.f; v.y = (nib & 2u) ? v.y : 0.f; v.z = (nib & 4u) ? v.z : 0.f; v.w = (nib & 8u) ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = v;
+                }
+                if (bits) {   // the ReLU's bit image: eight consecutive lanes hold the 32 columns of a word
+                    unsigned nib = 0;
+                    if (ok) nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                    unsigned wbits = nib << (4 * (c4 & 7));
+                    wbits |= __shfl_xor(wbits, 1);
+                    wbits |= __shfl_xor(wbits, 2);
+                    wbits |= __shfl_xor(wbits, 4);
+                    const int word = col >> 5;
+                    if ((c4 & 7) == 0 && row < g.M && word < g.ncb) bits[(long)row * g.ncb + word] = wbits;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (g.relu_bits == nullptr) {
         const unsigned* mask = (EXT && g.mask_bits) ? g.mask_bits + (long)bz * g.mask_batch : nullptr;
 #pragma unroll
@@ -415,6 +472,13 @@ int as_gemm_s6_nt_ext(const as_gemm* g, hipStream_t st) {
     k.k_seg = g->k_seg; k.nseg = g->k_seg ? g->K / g->k_seg : 1;
     k.a_seg_off = (const long*)g->a_seg_off; k.b_seg_off = (const long*)g->b_seg_off;
     k.colsum = g->colsum; k.colsum_batch = g->colsum_batch;
+    {
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        static const bool no_vec = AS_DIAG_SET("AS_S6_SCALAR_EPI");   // ablation: the one-column-per-lane epilogue
+        k.vec_epi = !no_vec && g->N % 4 == 0 && g->ldc % 4 == 0 && al16(g->C) && (g->c_off || g->c_batch % 4 == 0) &&
+                    (!g->bias || (al16(g->bias) && (g->bias_off || g->bias_batch % 4 == 0))) &&
+                    (!g->res || (al16(g->res) && g->res_ld % 4 == 0 && (g->res_off || g->res_batch % 4 == 0)));
+    }
     long blocks = (long)k.tiles_m * k.tiles_n * g->batch;
     if (blocks > (1L << 30)) return 0;
     k.batch = g->batch;
