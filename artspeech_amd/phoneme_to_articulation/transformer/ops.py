@@ -21,7 +21,7 @@ _SLAB = {}
 # "bf16x6" / "bf16x3" = fp32 operands split on the fly into 3 / 2 bf16 pieces on the bf16 MFMA, fp32 accumulation.
 # "lib" = the library's matrix arithmetic (as_set_matrix_arith: split fp32 on the bf16 matrix instruction unless the process chose
 # the exact fp32 one) for the forward linears, at any size.  Measured at configs[3] (d=256, L=6, B=32, T=200): forward + backward
-# 189.7 -> 175.8 ms; the full-width model's contours against the REFERENCE fixture then sit at 1.19 x the 1e-4 bound (0.89 x with
+# 186.8 -> 172.7 ms; the full-width model's contours against the REFERENCE fixture then sit at 1.19 x the 1e-4 bound (0.89 x with
 # "f32": two correct fp32 roundings of a 6-layer network differ by about that much), so the default stays "f32": by default only
 # the backward's GEMMs (input and weight gradients, GRAD_PRECISION below) use the split arithmetic.
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "lib": 3}
@@ -30,7 +30,7 @@ GEMM_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GEMM_PRECISION", "f32")]
 
 # Precision of the backward's GEMMs -- input gradients (dx = dz W, with their residual / ReLU-mask / segmented-reduction operands)
 # and weight gradients (dW = dz^T x with the bias gradient as fused column sums): the library's matrix arithmetic by default
-# (configs[3]: 218 ms all-fp32 -> 189.7 ms).  The parity tests hold gradients to a yardstick relative to their own magnitude and the split
+# (configs[3]: 218 ms all-fp32 -> 186.8 ms).  The parity tests hold gradients to a yardstick relative to their own magnitude and the split
 # product is at least as accurate as the fp32 instruction's (tests/test_gpu_parity.py::test_split_matrix_arithmetic_error_vs_fp64),
 # so nothing a forward value is compared with depends on this.  ARTSPEECH_GRAD_PRECISION=f32 keeps them on the fp32 instruction.
 GRAD_PRECISION = PRECISIONS[os.environ.get("ARTSPEECH_GRAD_PRECISION", "lib")]

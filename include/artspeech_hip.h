@@ -234,8 +234,8 @@ typedef struct as_gemm {
        forward (a_k == b_k == 1; plain or relu_bits epilogue), input gradient (a_k == 1, b_j == 1; with res / mask_bits / k_seg)
        and weight gradient (a_i == b_j == 1, >= 256 output tiles of 128 x 128; with colsum); linear or grouped batches,
        K % 16 == 0, float4-clean operands.  Anything else, and mode 0, as 0.  The transformer modules use it for every backward
-       GEMM (ARTSPEECH_GRAD_PRECISION, default "lib": 218 -> 190 ms at configs[3]) and offer it for the forward ones
-       (ARTSPEECH_GEMM_PRECISION=lib: 176 ms; the full-width contours then sit at 1.19 x the 1e-4 bound against the reference
+       GEMM (ARTSPEECH_GRAD_PRECISION, default "lib": 218 -> 187 ms at configs[3]) and offer it for the forward ones
+       (ARTSPEECH_GEMM_PRECISION=lib: 173 ms; the full-width contours then sit at 1.19 x the 1e-4 bound against the reference
        fixture, 0.89 x with 0: default 0). */
     int32_t precision;
     int32_t b_kshift_batch;
