@@ -175,6 +175,46 @@ def test_split_matrix_arithmetic_error_vs_fp64(dev, matrix_arith, M, N, K, act):
     assert err[1][0] <= 2e-6 * scale * max(1.0, np.sqrt(K / 256)), (err, scale)   # (fp32 accumulation over K: grows like sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,act", [(37, 130, 64, 1), (200, 45, 32, 2), (129, 258, 48, 0), (300, 128, 256, 1)])
+def test_split_general_kernel_forward_odd_outputs(dev, matrix_arith, M, N, K, act):
+    """gemm_s6.hip's forward orientation through as_gemm_f32(precision = 3) and as_linear_fwd(planes_ws = NULL) on outputs that are
+    NOT float4-clean (N % 4 != 0: the one-column-per-lane epilogue) and on clean ones (the row-major float4 epilogue), ragged
+    tile edges in both dimensions, with bias, activation and -- for ReLU -- the bit image."""
+    L = _lib.lib()
+    matrix_arith(1)
+    rng = np.random.RandomState(M + N + K)
+    a = rng.randn(M, K).astype(np.float32)
+    w = ((rng.rand(N, K) * 2 - 1) / np.sqrt(K)).astype(np.float32)
+    bias = ((rng.rand(N) * 2 - 1) / np.sqrt(K)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    ref = np.maximum(ref, 0) if act == 1 else (1 / (1 + np.exp(-ref)) if act == 2 else ref)
+    da, dw, db = T_(a, dev), T_(w, dev), T_(bias, dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(L.as_linear_fwd(_lib.ptr(da), K, _lib.ptr(dw), K, _lib.ptr(db), _lib.ptr(out), N, M, N, K, act, None, _lib.stream_ptr()))
+    tol = 2e-6 * max(1.0, np.abs(ref).max())
+    assert np.abs(out.cpu().numpy() - ref).max() <= tol
+    if act <= 1:
+        ncb = (N + 31) // 32
+        out2 = torch.full((M, N), float("nan"), device=dev)
+        bits = torch.full((M, ncb), -1, dtype=torch.int32, device=dev)
+        g = _lib.Gemm()
+        g.A, g.B, g.C, g.bias = da.data_ptr(), dw.data_ptr(), out2.data_ptr(), db.data_ptr()
+        g.M, g.N, g.K, g.batch = M, N, K, 1
+        g.a_i, g.a_k, g.b_j, g.b_k, g.ldc = K, 1, K, 1, N
+        g.act, g.precision = act, 3
+        if act == 1:
+            g.relu_bits, g.relu_bits_batch = bits.data_ptr(), M * ncb
+        _lib.check(L.as_gemm_f32(C.byref(g), _lib.stream_ptr()), "as_gemm_f32")
+        torch.cuda.synchronize()
+        got = out2.cpu().numpy()
+        assert np.abs(got - ref).max() <= tol
+        if act == 1:
+            words = bits.cpu().numpy().view(np.uint32)
+            img = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, ncb * 32)
+            assert (img[:, :N].astype(bool) == (got > 0)).all(), "ReLU bit image"
+            assert (img[:, N:] == 0).all(), "bits beyond N are clear"
+
+
 def test_split_matrix_arithmetic_heads_error_vs_fp64(dev, matrix_arith):
     """The fused head layers (Linear + ReLU + LayerNorm, lin_s6_kernel; output layer, lin_out_s6_kernel) in both arithmetics
     against the fp64 oracle of ArticulatorPredictor (encoder_decoder/models.py:7-33) at 6400 frames x 11 heads: the split
